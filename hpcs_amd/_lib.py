@@ -1,0 +1,133 @@
+"""ctypes binding of libhpcs_mi355x.so (include/hpcs_mi355x.h).
+
+There is NO CPU fallback: if the shared library is missing, or a tensor is not on a
+HIP device, the call raises.  The oracle (oracle/) is never imported from here.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libhpcs_mi355x.so")
+
+_P, _I, _L, _F, _Z, _U = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t, ctypes.c_uint64
+_KIND = {"p": _P, "i": _I, "l": _L, "f": _F, "z": _Z, "u": _U, "s": _P}
+
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "hpcs_mi355x.h")
+
+
+def _parse_header():
+    """Derives every entry point's ctypes signature from include/hpcs_mi355x.h (single source of truth).
+
+    kinds: p pointer, i int/int32, l int64, u uint64, z size_t, f float, s stream (filled in automatically).
+    """
+    import re
+    text = open(HEADER_PATH).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    sigs = {}
+    for ret, name, params in re.findall(r"\b(int|size_t)\s+(hpcs_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", text):
+        kinds = ""
+        for prm in [q.strip() for q in params.split(",")]:
+            if prm in ("", "void"):
+                continue
+            if "hpcs_stream_t" in prm:
+                kinds += "s"
+            elif "*" in prm:
+                kinds += "p"
+            elif "uint64_t" in prm:
+                kinds += "u"
+            elif "int64_t" in prm:
+                kinds += "l"
+            elif "size_t" in prm:
+                kinds += "z"
+            elif "float" in prm:
+                kinds += "f"
+            elif re.search(r"\b(int|int32_t)\b", prm):
+                kinds += "i"
+            else:
+                raise RuntimeError(f"cannot map parameter '{prm}' of {name}")
+        sigs[name] = (kinds, "z" if ret == "size_t" else "i")
+    return sigs
+
+
+SIGNATURES = _parse_header()
+
+_lib = None
+
+
+class HpcsNativeError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HpcsNativeError(
+                f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hpcs_amd has no CPU fallback)")
+        _lib = ctypes.CDLL(LIB_PATH)
+    return _lib
+
+
+_bound = {}
+
+
+def _fn(name):
+    f = _bound.get(name)
+    if f is None:
+        args, ret = SIGNATURES[name]
+        f = getattr(lib(), name)       # AttributeError here = header/library mismatch: fail loudly
+        f.argtypes = [_KIND[c] for c in args]
+        f.restype = _KIND[ret]
+        _bound[name] = f
+    return f
+
+
+_STATUS = {-1: "bad shape", -2: "unsupported configuration", -3: "workspace too small", -4: "null pointer"}
+
+
+def _dev_ptr(t):
+    if t is None:
+        return None
+    if not torch.is_tensor(t):
+        raise TypeError(f"expected a tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise HpcsNativeError("hpcs_amd kernels need tensors on a HIP device (no CPU fallback)")
+    if not t.is_contiguous():
+        raise HpcsNativeError("hpcs_amd kernels need contiguous tensors")
+    return t.data_ptr()
+
+
+def call(name, *args):
+    """Calls an entry point; tensors become device pointers, the stream argument is appended."""
+    kinds, ret = SIGNATURES[name]
+    fn = _fn(name)
+    conv = []
+    ai = 0
+    for c in kinds:
+        if c == "s":
+            conv.append(torch.cuda.current_stream().cuda_stream)
+            continue
+        a = args[ai]
+        ai += 1
+        if c == "p":
+            conv.append(a if (a is None or isinstance(a, int)) else _dev_ptr(a))
+        elif c == "f":
+            conv.append(float(a))
+        else:
+            conv.append(int(a))
+    if ai != len(args):
+        raise TypeError(f"{name}: expected {ai} arguments, got {len(args)}")
+    rc = fn(*conv)
+    if ret == "i" and name != "hpcs_version" and rc != 0:
+        msg = _STATUS.get(rc, f"HIP error {-(rc + 1000)}" if rc <= -1000 else "unknown")
+        raise HpcsNativeError(f"{name} failed: {msg} (status {rc})")
+    return rc
+
+
+def exported_symbols_declared_in_header():
+    """Names declared in include/hpcs_mi355x.h (used by the ABI test)."""
+    return sorted(SIGNATURES)

@@ -1,0 +1,51 @@
+// Shared helpers for the gfx950 kernels of libhpcs_mi355x.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/hpcs_mi355x.h"
+
+#define HPCS_WAVE 64
+
+#define HPCS_CHECK_LAUNCH()                                   \
+    do {                                                      \
+        hipError_t e__ = hipGetLastError();                   \
+        if (e__ != hipSuccess) return HPCS_ERR_HIP - (int)e__; \
+    } while (0)
+
+static inline int hpcs_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Bijective XCD-aware block remap (cdna_hip_programming.md T1): hardware deals consecutive
+// block ids round-robin over the 8 XCDs; give each XCD a contiguous run of logical ids so that
+// neighbouring tiles (which share operand panels) hit the same L2.
+__device__ __forceinline__ unsigned hpcs_xcd_remap(unsigned id, unsigned total) {
+    const unsigned q = total >> 3, r = total & 7u;
+    const unsigned xcd = id & 7u, slot = id >> 3;
+    const unsigned base = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
+    return base + slot;
+}
+
+__device__ __forceinline__ float hpcs_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double hpcs_wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Block-wide sum for blockDim.x a multiple of 64 (<= 1024).  Result valid in thread 0.
+template <typename T>
+__device__ __forceinline__ T hpcs_block_sum(T v, T* smem /* >= 16 entries */) {
+    v = hpcs_wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) smem[w] = v;
+    __syncthreads();
+    T r = T(0);
+    if (threadIdx.x == 0)
+        for (int i = 0; i < nw; ++i) r += smem[i];
+    return r;
+}

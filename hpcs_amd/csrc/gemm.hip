@@ -1,0 +1,320 @@
+// Channel-mixing GEMMs on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, k-ordered fma chain).
+//
+// Replaces nn.Linear-over-channels (map_to_feat / map_to_dir, vn_layers.py:14-24,48-77) and the
+// Conv1d(k=1) heads (vn_dgcnn_partseg.py:40-57) of the reference, forward and backward:
+//   gemm_tn : C[b] = At^T * B[b]          forward (At = W^T) and data-grad (At = W)
+//   gemm_nt : dW   = sum_b G[b] * X[b]^T  weight-grad, deterministic split reduction
+//
+// Tiling (wave64): workgroup tile BM x BN, WM x WN waves, each wave owns (BM/WM) x (BN/WN) as 32x32
+// MFMA tiles.  Both operands are staged K-major in LDS ([k][m] / [k][n]) so every MFMA operand fetch is one
+// conflict-free ds_read_b32 per lane (lanes 0-31 = 32 consecutive floats of row k, lanes 32-63 = row k+1).
+// Global->LDS goes through registers, double-buffered, one barrier per K step.
+// Block ids are remapped so that the row tiles sharing one activation panel run on the same XCD (L2 reuse).
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float4 ld4_guard(const float* __restrict__ rowp, int col, int ncols, bool rowok,
+                                            bool vec) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!rowok) return v;
+    if (vec && col + 3 < ncols) return *reinterpret_cast<const float4*>(rowp + col);
+    if (col < ncols) v.x = rowp[col];
+    if (col + 1 < ncols) v.y = rowp[col + 1];
+    if (col + 2 < ncols) v.z = rowp[col + 2];
+    if (col + 3 < ncols) v.w = rowp[col + 3];
+    return v;
+}
+
+template <int BM, int BN, int BK, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_tn_kernel(
+    const float* __restrict__ At, int lda, const float* __restrict__ Bm, int ldb, int64_t sBo, int64_t sBi,
+    float* __restrict__ C, int ldc, int64_t sCo, int64_t sCi, int M, int Nc, int K, int n_inner,
+    const float* __restrict__ rowbias, int accumulate, int tilesM, int tilesN, unsigned total, int vecA,
+    int vecB) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int A_LD = BK * BM / 4 / NT, B_LD = BK * BN / 4 / NT;
+    static_assert(A_LD >= 1 && B_LD >= 1, "tile too small for the thread count");
+    __shared__ float As[2][BK][BM];
+    __shared__ float Bs[2][BK][BN];
+
+    const unsigned logical = hpcs_xcd_remap(blockIdx.x, total);
+    const int rowTile = logical % tilesM;
+    const unsigned t1 = logical / tilesM;
+    const int colTile = t1 % tilesN;
+    const int batch = t1 / tilesN;
+    const int bo = batch / n_inner, bi = batch % n_inner;
+    const float* Bp = Bm + bo * sBo + bi * sBi;
+    float* Cp = C + bo * sCo + bi * sCi;
+    const int m0 = rowTile * BM, n0 = colTile * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[A_LD], rb[B_LD];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            const int f = tid + i * NT, row = f / (BM / 4), c4 = (f % (BM / 4)) * 4;
+            ra[i] = ld4_guard(At + (int64_t)(k0 + row) * lda, m0 + c4, M, k0 + row < K, vecA);
+        }
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) {
+            const int f = tid + i * NT, row = f / (BN / 4), c4 = (f % (BN / 4)) * 4;
+            rb[i] = ld4_guard(Bp + (int64_t)(k0 + row) * ldb, n0 + c4, Nc, k0 + row < K, vecB);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            const int f = tid + i * NT, row = f / (BM / 4), c4 = (f % (BM / 4)) * 4;
+            *reinterpret_cast<float4*>(&As[buf][row][c4]) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) {
+            const int f = tid + i * NT, row = f / (BN / 4), c4 = (f % (BN / 4)) * 4;
+            *reinterpret_cast<float4*>(&Bs[buf][row][c4]) = rb[i];
+        }
+    };
+
+    const int nk = (K + BK - 1) / BK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    const int lr = lane & 31, lk = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload((kt + 1) * BK);
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = As[buf][kk * 2 + lk][wm * (BM / WM) + i * 32 + lr];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Bs[buf][kk * 2 + lk][wn * (BN / WN) + j * 32 + lr];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    const float* bias = rowbias ? rowbias + (int64_t)batch * M : nullptr;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * (BN / WN) + j * 32 + lr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (row < M && col < Nc) {
+                    float v = acc[i][j][r];
+                    if (bias) v += bias[row];
+                    float* dst = Cp + (int64_t)row * ldc + col;
+                    if (accumulate) v += *dst;
+                    *dst = v;
+                }
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// weight-grad: both operands have the reduction index (columns) contiguous.  LDS rows padded to BKC+1 so the
+// 32 lanes of an operand fetch (32 different rows, same column) hit 32 different banks.
+template <int BM, int BN, int BKC, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(
+    const float* __restrict__ G, int ldg, int64_t sGo, int64_t sGi, const float* __restrict__ X, int ldx,
+    int64_t sXo, int64_t sXi, int M, int Kx, int Nc, int n_inner, int n_batch, int chunk, int units_per_batch,
+    int nsplit, float* __restrict__ part, int tilesM, int tilesK, int vecG, int vecX) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int LD = BKC + 1;
+    constexpr int G_LD = BM * BKC / 4 / NT, X_LD = BN * BKC / 4 / NT;
+    __shared__ float Gs[BM][LD];
+    __shared__ float Xs[BN][LD];
+
+    const int tile = blockIdx.x % (tilesM * tilesK);
+    const int split = blockIdx.x / (tilesM * tilesK);
+    const int rowTile = tile % tilesM, colTile = tile / tilesM;
+    const int m0 = rowTile * BM, x0 = colTile * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lr = lane & 31, lk = lane >> 5;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int64_t units = (int64_t)n_batch * units_per_batch;
+    for (int64_t u = split; u < units; u += nsplit) {
+        const int batch = (int)(u / units_per_batch);
+        const int c_begin = (int)(u % units_per_batch) * chunk;
+        const int c_end = min(Nc, c_begin + chunk);
+        const int bo = batch / n_inner, bi = batch % n_inner;
+        const float* Gp = G + bo * sGo + bi * sGi;
+        const float* Xp = X + bo * sXo + bi * sXi;
+        for (int c0 = c_begin; c0 < c_end; c0 += BKC) {
+            float4 rg[G_LD], rx[X_LD];
+#pragma unroll
+            for (int i = 0; i < G_LD; ++i) {
+                const int f = tid + i * NT, row = f / (BKC / 4), c4 = (f % (BKC / 4)) * 4;
+                rg[i] = ld4_guard(Gp + (int64_t)(m0 + row) * ldg, c0 + c4, c_end, m0 + row < M, vecG);
+            }
+#pragma unroll
+            for (int i = 0; i < X_LD; ++i) {
+                const int f = tid + i * NT, row = f / (BKC / 4), c4 = (f % (BKC / 4)) * 4;
+                rx[i] = ld4_guard(Xp + (int64_t)(x0 + row) * ldx, c0 + c4, c_end, x0 + row < Kx, vecX);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < G_LD; ++i) {
+                const int f = tid + i * NT, row = f / (BKC / 4), c4 = (f % (BKC / 4)) * 4;
+                Gs[row][c4] = rg[i].x; Gs[row][c4 + 1] = rg[i].y; Gs[row][c4 + 2] = rg[i].z; Gs[row][c4 + 3] = rg[i].w;
+            }
+#pragma unroll
+            for (int i = 0; i < X_LD; ++i) {
+                const int f = tid + i * NT, row = f / (BKC / 4), c4 = (f % (BKC / 4)) * 4;
+                Xs[row][c4] = rx[i].x; Xs[row][c4 + 1] = rx[i].y; Xs[row][c4 + 2] = rx[i].z; Xs[row][c4 + 3] = rx[i].w;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < BKC / 2; ++kk) {
+                float a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = Gs[wm * (BM / WM) + i * 32 + lr][kk * 2 + lk];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = Xs[wn * (BN / WN) + j * 32 + lr][kk * 2 + lk];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+    float* P = part + (int64_t)split * M * Kx;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = x0 + wn * (BN / WN) + j * 32 + lr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (row < M && col < Kx) P[(int64_t)row * Kx + col] = acc[i][j][r];
+            }
+        }
+}
+
+__global__ void split_reduce_kernel(const float* __restrict__ part, int nsplit, int M, int Kx, float* __restrict__ dW,
+                                    int lddw, int accumulate) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (int64_t)M * Kx) return;
+    float s = 0.f;
+    for (int i = 0; i < nsplit; ++i) s += part[(int64_t)i * M * Kx + e];   // fixed order: deterministic
+    const int row = (int)(e / Kx), col = (int)(e % Kx);
+    float* d = dW + (int64_t)row * lddw + col;
+    *d = accumulate ? *d + s : s;
+}
+
+constexpr int NT_BM = 64, NT_BN = 64, NT_BKC = 32;
+
+struct NtPlan { int tilesM, tilesK, chunk, units_per_batch, nsplit; };
+NtPlan nt_plan(int M, int Kx, int Nc, int n_batch) {
+    NtPlan p;
+    p.tilesM = hpcs_cdiv(M, NT_BM);
+    p.tilesK = hpcs_cdiv(Kx, NT_BN);
+    p.chunk = 2048;
+    p.units_per_batch = hpcs_cdiv(Nc, p.chunk);
+    const long units = (long)n_batch * p.units_per_batch;
+    long want = 2048 / ((long)p.tilesM * p.tilesK);
+    if (want < 1) want = 1;
+    p.nsplit = (int)(units < want ? units : want);
+    if (p.nsplit < 1) p.nsplit = 1;
+    return p;
+}
+
+inline bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
+
+}  // namespace
+
+extern "C" int hpcs_gemm_tn(const float* At, int lda, const float* Bm, int ldb, int64_t strideB_o, int64_t strideB_i,
+                            float* C, int ldc, int64_t strideC_o, int64_t strideC_i, int M, int Nc, int K, int n_outer,
+                            int n_inner, const float* rowbias, int accumulate, hpcs_stream_t stream) {
+    if (!At || !Bm || !C) return HPCS_ERR_NULL;
+    if (M <= 0 || Nc <= 0 || K <= 0 || n_outer < 0 || n_inner <= 0 || lda < M || ldb < Nc || ldc < Nc)
+        return HPCS_ERR_SHAPE;
+    if (n_outer == 0) return HPCS_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int vecA = (lda % 4 == 0) && aligned16(At);
+    const int vecB = (ldb % 4 == 0) && (strideB_o % 4 == 0) && (strideB_i % 4 == 0) && aligned16(Bm);
+    const int nb = n_outer * n_inner;
+    if (M > 64) {
+        constexpr int BM = 128, BN = 128, BK = 16;
+        const int tm = hpcs_cdiv(M, BM), tn = hpcs_cdiv(Nc, BN);
+        const long total = (long)tm * tn * nb;
+        if (total > 0x7fffffffL) return HPCS_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, BK, 2, 2>), dim3((unsigned)total), dim3(256), 0, st, At, lda, Bm,
+                           ldb, strideB_o, strideB_i, C, ldc, strideC_o, strideC_i, M, Nc, K, n_inner, rowbias,
+                           accumulate, tm, tn, (unsigned)total, vecA, vecB);
+    } else {
+        constexpr int BM = 64, BN = 128, BK = 16;
+        const int tm = hpcs_cdiv(M, BM), tn = hpcs_cdiv(Nc, BN);
+        const long total = (long)tm * tn * nb;
+        if (total > 0x7fffffffL) return HPCS_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, BK, 1, 4>), dim3((unsigned)total), dim3(256), 0, st, At, lda, Bm,
+                           ldb, strideB_o, strideB_i, C, ldc, strideC_o, strideC_i, M, Nc, K, n_inner, rowbias,
+                           accumulate, tm, tn, (unsigned)total, vecA, vecB);
+    }
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
+extern "C" size_t hpcs_gemm_nt_workspace(int M, int Kx, int Nc, int n_outer, int n_inner) {
+    if (M <= 0 || Kx <= 0 || Nc <= 0 || n_outer <= 0 || n_inner <= 0) return 0;
+    const NtPlan p = nt_plan(M, Kx, Nc, n_outer * n_inner);
+    return (size_t)p.nsplit * M * Kx * sizeof(float);
+}
+
+extern "C" int hpcs_gemm_nt(const float* G, int ldg, int64_t strideG_o, int64_t strideG_i, const float* X, int ldx,
+                            int64_t strideX_o, int64_t strideX_i, int M, int Kx, int Nc, int n_outer, int n_inner,
+                            float* dW, int lddw, int accumulate, void* ws, size_t ws_bytes, hpcs_stream_t stream) {
+    if (!G || !X || !dW || !ws) return HPCS_ERR_NULL;
+    if (M <= 0 || Kx <= 0 || Nc <= 0 || n_outer <= 0 || n_inner <= 0 || ldg < Nc || ldx < Nc || lddw < Kx)
+        return HPCS_ERR_SHAPE;
+    const int nb = n_outer * n_inner;
+    const NtPlan p = nt_plan(M, Kx, Nc, nb);
+    if (ws_bytes < (size_t)p.nsplit * M * Kx * sizeof(float)) return HPCS_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int vecG = (ldg % 4 == 0) && (strideG_o % 4 == 0) && (strideG_i % 4 == 0) && aligned16(G);
+    const int vecX = (ldx % 4 == 0) && (strideX_o % 4 == 0) && (strideX_i % 4 == 0) && aligned16(X);
+    const long blocks = (long)p.tilesM * p.tilesK * p.nsplit;
+    hipLaunchKernelGGL((gemm_nt_kernel<NT_BM, NT_BN, NT_BKC, 2, 2>), dim3((unsigned)blocks), dim3(256), 0, st, G, ldg,
+                       strideG_o, strideG_i, X, ldx, strideX_o, strideX_i, M, Kx, Nc, n_inner, nb, p.chunk,
+                       p.units_per_batch, p.nsplit, (float*)ws, p.tilesM, p.tilesK, vecG, vecX);
+    HPCS_CHECK_LAUNCH();
+    const int64_t ne = (int64_t)M * Kx;
+    hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)hpcs_cdiv(ne, 256)), dim3(256), 0, st, (const float*)ws,
+                       p.nsplit, M, Kx, dW, lddw, accumulate);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}

@@ -1,0 +1,222 @@
+/* libhpcs_mi355x.so -- C ABI of the MI355X (gfx950) kernels behind the HPCS operator API.
+ *
+ * The reference (TheCrossProduct/HPCS) has no FFI boundary: its hot path is plain
+ * torch modules/functions.  This library is the native layer the build adds UNDER
+ * that Python surface; each entry point names the reference
+ * code it replaces (paths relative to the reference repository root).
+ *
+ * Conventions (all entry points):
+ *   - raw DEVICE pointers to contiguous fp32 / int64 / int32 buffers owned by the caller;
+ *   - enqueue-only on `stream` (a hipStream_t passed as void*): no allocation, no host
+ *     sync, no global state; re-entrant;
+ *   - returns HPCS_OK or a negative hpcs_status; HIP launch errors come back as
+ *     HPCS_ERR_HIP - hipError_t;
+ *   - tensors keep the reference's layouts: vector-neuron features are [B, C, 3, L]
+ *     with L = N (points) or N*k (edges), L contiguous.
+ */
+#ifndef HPCS_MI355X_H
+#define HPCS_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* hpcs_stream_t;
+
+enum hpcs_status {
+    HPCS_OK = 0,
+    HPCS_ERR_SHAPE = -1,       /* negative/zero/inconsistent dimension */
+    HPCS_ERR_UNSUPPORTED = -2, /* e.g. k > 64 */
+    HPCS_ERR_WORKSPACE = -3,   /* workspace too small */
+    HPCS_ERR_NULL = -4,        /* required pointer is NULL */
+    HPCS_ERR_HIP = -1000       /* HPCS_ERR_HIP - hipError_t */
+};
+
+int hpcs_version(void);
+
+/* ---- a1: knn(x, k)  hpcs/nn/dgcnn/utils/vn_dgcnn_util.py:4-10 ------------------------------
+ * x [B,D,N] -> idx [B,N,k] int64: the k largest of  (-|xj|^2 - (-2 xi.xj)) - |xi|^2  per row,
+ * nearest first, ties by ascending index.  Rounding sequence = torch CPU. k <= 64. */
+int hpcs_knn(const float* x, int B, int D, int N, int k, int64_t* idx, hpcs_stream_t stream);
+
+/* ---- a2: get_graph_feature  hpcs/nn/dgcnn/utils/vn_dgcnn_util.py:13-41 ----------------------
+ * x [B,C,3,N], idx [B,N,k] (cloud-local) -> out [B,2C,3,N,k] = (x[nbr]-x[ctr], x[ctr]).
+ * bwd: gx [B,C,3,N] is overwritten (scatter-add over neighbours uses fp32 atomics). */
+int hpcs_edge_gather_fwd(const float* x, const int64_t* idx, int B, int C, int N, int k, float* out,
+                         hpcs_stream_t stream);
+int hpcs_edge_gather_bwd(const float* gout, const int64_t* idx, int B, int C, int N, int k, float* gx,
+                         hpcs_stream_t stream);
+
+/* ---- channel mixing (nn.Linear over the channel axis / Conv1d k=1) -----------------------------
+ * replaces map_to_feat / map_to_dir of vn_layers.py:14-24,48-77 and the Conv1d's of
+ * vn_dgcnn_partseg.py:40-57.  fp32 MFMA (v_mfma_f32_32x32x2_f32), exact k-ordered fma chain.
+ *
+ * hpcs_gemm_tn:  C[b] (M x Nc) (+)= At^T (At is K x M, row stride lda) * Bm[b] (K x Nc, row stride ldb)
+ *                + rowbias[b][m] (optional).  Batch index b = bo*n_inner + bi addresses
+ *                Bm + bo*strideB_o + bi*strideB_i (same for C), so a [B,C,3,N] tensor can be
+ *                walked as 3B matrices of N columns.
+ * hpcs_gemm_nt:  dW (M x Kx, row stride lddw) (+)= sum_b G[b] (M x Nc) * X[b]^T (Kx x Nc).
+ *                Deterministic split reduction through `ws` (hpcs_gemm_nt_workspace bytes). */
+int hpcs_gemm_tn(const float* At, int lda, const float* Bm, int ldb, int64_t strideB_o, int64_t strideB_i,
+                 float* C, int ldc, int64_t strideC_o, int64_t strideC_i, int M, int Nc, int K, int n_outer,
+                 int n_inner, const float* rowbias, int accumulate, hpcs_stream_t stream);
+size_t hpcs_gemm_nt_workspace(int M, int Kx, int Nc, int n_outer, int n_inner);
+int hpcs_gemm_nt(const float* G, int ldg, int64_t strideG_o, int64_t strideG_i, const float* X, int ldx,
+                 int64_t strideX_o, int64_t strideX_i, int M, int Kx, int Nc, int n_outer, int n_inner, float* dW,
+                 int lddw, int accumulate, void* ws, size_t ws_bytes, hpcs_stream_t stream);
+
+/* ---- a3: VNLinearLeakyReLU / VNBatchNorm / VNLeakyReLU  vn_layers.py:27-77,112-132 -----------
+ * PD [B, Cout+Cd, 3, L]: rows [0,Cout) = p = W_feat x, rows [Cout,Cout+Cd) = d = W_dir x
+ * (Cd = Cout, or 1 for share_nonlinearity).  flags: HPCS_VN_BN | HPCS_VN_LRELU.
+ *   norm_stats : sums[2*Cout] (double; sum n, sum n^2 with n = |p|+1e-6), overwritten
+ *   bn_finalize: batch stats -> mean/rstd (+ running-stat update, momentum 0.1, unbiased var);
+ *                training=0 -> mean/rstd from the running stats
+ *   apply_fwd  : out [B,Cout,3,L]  (pool_k>0: mean over groups of pool_k consecutive l -> [B,Cout,3,L/pool_k],
+ *                i.e. mean_pool of vn_layers.py:152-153 fused)
+ *   bwd_reduce : red[2*Cout] (double; sum g_nb = dbeta, sum g_nb*xhat = dgamma), overwritten
+ *   bwd_apply  : GPD [B,Cout+Cd,3,L] = (dL/dp, dL/dd) */
+#define HPCS_VN_BN 1
+#define HPCS_VN_LRELU 2
+int hpcs_vn_norm_stats(const float* PD, int B, int Cout, int Ctot, int64_t L, double* sums, hpcs_stream_t stream);
+int hpcs_bn_finalize(const double* sums, int C, int64_t count, float eps, float momentum, float* running_mean,
+                     float* running_var, float* mean, float* rstd, int training, hpcs_stream_t stream);
+int hpcs_vn_apply_fwd(const float* PD, const float* mean, const float* rstd, const float* gamma,
+                      const float* beta, int B, int Cout, int Cd, int64_t L, int pool_k, float slope, int flags,
+                      float* out, hpcs_stream_t stream);
+int hpcs_vn_bwd_reduce(const float* PD, const float* gout, const float* mean, const float* rstd,
+                       const float* gamma, const float* beta, int B, int Cout, int Cd, int64_t L, int pool_k,
+                       float slope, int flags, double* red, hpcs_stream_t stream);
+int hpcs_vn_bwd_apply(const float* PD, const float* gout, const float* mean, const float* rstd,
+                      const float* gamma, const float* beta, const double* red, int training, int B, int Cout,
+                      int Cd, int64_t L, int pool_k, float slope, int flags, float* GPD, hpcs_stream_t stream);
+
+/* ---- Conv1d(k=1)+BatchNorm1d(+LeakyReLU)(+Dropout mask)  vn_dgcnn_partseg.py:40-57,97-102 ------
+ * Y [B,C,L] is the Conv1d output (hpcs_gemm_tn).  slope = 1 means no activation; mask (nullable,
+ * [B,C,L]) is the already scaled dropout multiplier. */
+int hpcs_bn_stats(const float* Y, int B, int C, int64_t L, double* sums, hpcs_stream_t stream);
+int hpcs_bn_act_fwd(const float* Y, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                    const float* mask, int B, int C, int64_t L, float slope, float* out, hpcs_stream_t stream);
+int hpcs_bn_act_bwd_reduce(const float* Y, const float* gout, const float* mean, const float* rstd,
+                           const float* gamma, const float* beta, const float* mask, int B, int C, int64_t L,
+                           float slope, double* red, hpcs_stream_t stream);
+int hpcs_bn_act_bwd_apply(const float* Y, const float* gout, const float* mean, const float* rstd,
+                          const float* gamma, const float* beta, const float* mask, const double* red,
+                          int training, int B, int C, int64_t L, float slope, float* gY, hpcs_stream_t stream);
+
+/* ---- a4/a5/a6 glue of VN_DGCNN_partseg.forward  vn_dgcnn_partseg.py:79-95 ---------------------
+ * concat_mean   : x [B,C,3,N] -> out [B,2C,3,N] = (x, mean_N(x) expanded)          (:82-83)
+ * frame_project : einsum('bijm,bjkm->bikm', x [B,C,3,N], z [B,3,3,N])               (:85, vn_layers.py:197)
+ * rowmax        : x [rows,L] -> max over L (+ int32 argmax)                          (:87)
+ * rowsum        : x [rows,L] -> sum over L */
+int hpcs_concat_mean_fwd(const float* x, int B, int C, int N, float* out, hpcs_stream_t stream);
+int hpcs_concat_mean_bwd(const float* gout, int B, int C, int N, float* gx, hpcs_stream_t stream);
+int hpcs_frame_project_fwd(const float* x, const float* z, int B, int C, int N, float* out, hpcs_stream_t stream);
+int hpcs_frame_project_bwd(const float* x, const float* z, const float* gout, int B, int C, int N, float* gx,
+                           float* gz, hpcs_stream_t stream);
+int hpcs_rowmax_fwd(const float* x, int64_t rows, int64_t L, float* out, int32_t* arg, hpcs_stream_t stream);
+int hpcs_rowmax_bwd(const float* gout, const int32_t* arg, int64_t rows, int64_t L, float* gx,
+                    hpcs_stream_t stream);
+int hpcs_rowsum(const float* x, int64_t rows, int64_t L, float scale, float* out, hpcs_stream_t stream);
+/* VNMaxPool  vn_layers.py:135-149: x [B,C,3,N,k], d = W x [B,C,3,N,k] -> out [B,C,3,N], arg [B,C,N] */
+int hpcs_vn_maxpool_fwd(const float* x, const float* d, int B, int C, int N, int k, float* out, int32_t* arg,
+                        hpcs_stream_t stream);
+int hpcs_vn_maxpool_bwd(const float* gout, const int32_t* arg, int B, int C, int N, int k, float* gx,
+                        hpcs_stream_t stream);
+
+/* ---- a7 + Poincare toolbox  hpcs/utils/poincare.py:16-136, hpcs/utils/math.py:61-82 -----------
+ * Row-wise over the last dim E of [rows,E]. */
+int hpcs_expmap0_fwd(const float* u, int64_t rows, int E, float* out, hpcs_stream_t stream);
+int hpcs_expmap0_bwd(const float* u, const float* gout, int64_t rows, int E, float* gu, hpcs_stream_t stream);
+int hpcs_expmap_fwd(const float* u, const float* p, int64_t rows, int E, float* out, hpcs_stream_t stream);
+int hpcs_project(const float* x, int64_t rows, int E, float* out, hpcs_stream_t stream);
+int hpcs_mobius_add(const float* x, const float* y, int64_t rows, int E, float* out, hpcs_stream_t stream);
+int hpcs_hyp_dist_o(const float* x, int64_t rows, int E, float* out, hpcs_stream_t stream);
+/* a11: hyp_lca(a,b,return_coord=False)  hpcs/distances/lca.py:8-52 -> dist [rows]; optional coord [rows,E] */
+int hpcs_hyp_lca_fwd(const float* a, const float* b, int64_t rows, int E, float* dist, float* coord,
+                     hpcs_stream_t stream);
+int hpcs_hyp_lca_bwd(const float* a, const float* b, const float* gdist, int64_t rows, int E, float* ga, float* gb,
+                     hpcs_stream_t stream);
+/* a15: HyperbolicDistance.compute_mat  hpcs/distances/poincare.py:144-176 -> sim [M,M'] */
+int hpcs_hyperbolic_sim_mat(const float* x, const float* y, int M, int Mp, int E, float* out, hpcs_stream_t stream);
+
+/* ---- a8-a14: miner and losses -----------------------------------------------------------------
+ * All matrix-free: the (B*N)^2 cosine matrix of hpcs/loss/ultrametric_loss.py:65 is never built.
+ *
+ * l2_rows        : xn = x / max(|x|,1e-12)  (PML BaseDistance normalisation; hpcs/distances/cosine.py:6-8)
+ * cosine_mat     : 0.5*(1 + xn yn^T) [M,M']  (API completeness: CosineSimilarity.compute_mat, cosine.py:10-13)
+ * class_index    : labels [M] int64 in [0,C) -> order [M] int32 (members grouped by class, ascending index),
+ *                  offsets [C+1] int32                          (loss_and_miner_utils.py:13-21)
+ * sample_triplets: per class plan (host-computed: anchor-triplet offsets, k_l) -> a,p,n [T] int64.
+ *                  draws != NULL: use host draws (parity mode: identical to the reference's CPU
+ *                  torch.randint stream); draws == NULL: device counter-based RNG (seed).   (:23-71)
+ * triplet_filter : keep[t] from margin = cos(a,p)-cos(a,n) and (margin, kind); stable compaction
+ *                  -> a',p',n' [T'] and count on device      (triplet_margin_miner.py:13-38)
+ * hyphc          : per-triplet HypHC term + closed-form mean of the similarity matrix
+ *                  (ultrametric_loss.py:57-93)
+ * cosface        : PML CosFaceLoss (mirror: hierarchical_cosface_loss.py:57-87)
+ * triplet_margin : TripletMarginLoss + AvgNonZeroReducer      (triplet_margin_loss.py:34-65) */
+int hpcs_l2_rows_fwd(const float* x, int64_t rows, int E, float* xn, float* inv_norm, hpcs_stream_t stream);
+int hpcs_l2_rows_bwd(const float* xn, const float* inv_norm, const float* gxn, int64_t rows, int E, float* gx,
+                     int accumulate, hpcs_stream_t stream);
+int hpcs_cosine_mat(const float* xn, const float* yn, int M, int Mp, int E, float* out, hpcs_stream_t stream);
+int hpcs_class_index(const int64_t* labels, int M, int C, int32_t* order, int32_t* offsets, int32_t* counts_ws,
+                     hpcs_stream_t stream);
+int hpcs_sample_triplets(const int32_t* order, const int32_t* offsets, const int64_t* cls_toff,
+                         const int32_t* cls_k, int C, int M, int64_t T, const int64_t* draws_pos,
+                         const int64_t* draws_neg, uint64_t seed, int64_t* a, int64_t* p, int64_t* n,
+                         hpcs_stream_t stream);
+#define HPCS_TRIPLETS_ALL 0
+#define HPCS_TRIPLETS_EASY 1
+#define HPCS_TRIPLETS_SEMIHARD 2
+#define HPCS_TRIPLETS_HARD 3
+size_t hpcs_triplet_filter_workspace(int64_t T);
+int hpcs_triplet_filter(const float* xn, int E, const int64_t* a, const int64_t* p, const int64_t* n, int64_t T,
+                        float margin, int kind, int64_t* a_out, int64_t* p_out, int64_t* n_out, int64_t* count,
+                        void* ws, size_t ws_bytes, hpcs_stream_t stream);
+/* hyphc: count (device int64, may be < T_cap) triplets.  fwd writes loss_sum[1] (double; sum over triplets of
+ * sum(w) - sum(w*softmax(d/temp))).  bwd accumulates into gxn [M,E] (grad wrt unit rows, fp32 atomics) and
+ * gscale[1] (double).  gloss is dL/d(mean term) / count applied by the kernel: upstream * 1/count. */
+int hpcs_hyphc_fwd(const float* xn, int E, const int64_t* a, const int64_t* p, const int64_t* n,
+                   const int64_t* count, int64_t T_cap, const float* scale, float temperature, double* loss_sum,
+                   hpcs_stream_t stream);
+int hpcs_hyphc_bwd(const float* xn, int E, const int64_t* a, const int64_t* p, const int64_t* n,
+                   const int64_t* count, int64_t T_cap, const float* scale, float temperature,
+                   const float* gloss, float* gxn, double* gscale, hpcs_stream_t stream);
+/* mean of the M x M similarity in closed form: 0.5 + 0.5*|sum_i xn_i|^2/M^2.  colsum [E] double. */
+int hpcs_colsum(const float* xn, int64_t rows, int E, double* colsum, hpcs_stream_t stream);
+int hpcs_cosface_fwd(const float* xn, const float* wn, const int64_t* labels, int M, int E, int C, float margin,
+                     float scale, float* logits, float* loss_rows, hpcs_stream_t stream);
+int hpcs_cosface_bwd(const float* xn, const float* wn, const int64_t* labels, const float* logits, int M, int E,
+                     int C, float scale, float gscale_over_M, float* gxn, float* gwn, hpcs_stream_t stream);
+int hpcs_triplet_margin_fwd(const float* xn, int E, const int64_t* a, const int64_t* p, const int64_t* n,
+                            const int64_t* count, int64_t T_cap, float margin, double* sum_and_nnz,
+                            hpcs_stream_t stream);
+int hpcs_triplet_margin_bwd(const float* xn, int E, const int64_t* a, const int64_t* p, const int64_t* n,
+                            const int64_t* count, int64_t T_cap, float margin, const double* sum_and_nnz,
+                            const float* gloss, float* gxn, hpcs_stream_t stream);
+
+/* ---- next row f1: hpcs.optim.RAdam.step  hpcs/optim/radam.py:59-134 ---------------------------
+ * One fused launch over a table of tensors.  desc[i] = {param, grad, exp_avg, exp_avg_sq, rows, cols}
+ * (device pointers as uint64, rows*cols elements, `cols` = size of the last dim = the "point").
+ * step_sizes[i] = lr*sqrt(1-b2^t)/(1-b1^t) with the reference's per-parameter double increment of
+ * group["step"] (host-computed).  Applies egrad2rgrad, moment updates, expmap retraction, project
+ * (row-norm clip 1-4e-3) and parallel transport of exp_avg. */
+typedef struct {
+    uint64_t param, grad, exp_avg, exp_avg_sq;
+    int64_t rows;
+    int32_t cols;
+    float step_size;
+} hpcs_radam_desc;
+int hpcs_radam_step(const hpcs_radam_desc* desc_dev, int n_tensors, int64_t total_rows_hint, float beta1,
+                    float beta2, float eps, float weight_decay, hpcs_stream_t stream);
+
+/* flat fp32 helpers used by the data-parallel wrapper (gradient bucket pack/unpack+scale) */
+int hpcs_scale_inplace(float* x, int64_t n, float s, hpcs_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HPCS_MI355X_H */

@@ -1,0 +1,91 @@
+"""GPU parity: kNN (bit-exact vs the oracle) and the MFMA GEMMs, called through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+from _det import det_cloud, det_normalish, det_uniform
+from hpcs_amd import _lib
+from oracle import extractor as OE
+
+pytestmark = pytest.mark.gpu
+dev = "cuda"
+
+
+def hip_knn(x, k):
+    B, D, N = x.shape
+    idx = torch.empty(B, N, k, dtype=torch.int64, device=dev)
+    _lib.call("hpcs_knn", x.to(dev).contiguous(), B, D, N, k, idx)
+    return idx.cpu()
+
+
+@pytest.mark.parametrize("B,D,N,k,seed", [(2, 3, 256, 10, 11), (4, 3, 1024, 20, 14), (2, 63, 256, 10, 12),
+                                          (2, 63, 1024, 20, 15), (1, 3, 100, 7, 16), (2, 6, 77, 5, 17),
+                                          (1, 3, 2048, 40, 18), (1, 63, 2048, 40, 19), (3, 3, 64, 64, 20)])
+def test_knn_bit_exact(B, D, N, k, seed):
+    x = det_cloud(B, N, seed) if D == 3 else det_normalish((B, D, N), seed)
+    want = OE.knn_exact(x, k)
+    got = hip_knn(x, k)
+    assert torch.equal(got, want)
+
+
+def test_knn_duplicates_and_golden(golden):
+    x = det_cloud(2, 128, 13, dup_every=5)
+    assert torch.equal(hip_knn(x, 8), OE.knn_exact(x, 8))
+    x = det_cloud(2, 256, 11)
+    assert np.array_equal(hip_knn(x, 10).numpy(), golden["knn_d3_idx"].astype(np.int64))
+    x = det_normalish((2, 63, 256), 12)
+    assert np.array_equal(hip_knn(x, 10).numpy(), golden["knn_d63_idx"].astype(np.int64))
+
+
+def test_knn_errors():
+    x = torch.zeros(1, 3, 16, device=dev)
+    idx = torch.empty(1, 16, 20, dtype=torch.int64, device=dev)
+    with pytest.raises(_lib.HpcsNativeError):
+        _lib.call("hpcs_knn", x, 1, 3, 16, 20, idx)       # k > N
+    with pytest.raises(_lib.HpcsNativeError):
+        _lib.call("hpcs_knn", torch.zeros(1, 3, 16), 1, 3, 16, 4, idx)   # CPU tensor: no fallback
+
+
+@pytest.mark.parametrize("M,K,Nc,nb", [(21, 2, 300, 3), (42, 42, 1024, 2), (341, 63, 3 * 256, 2),
+                                       (682, 682, 3 * 128, 2), (256, 189, 1024, 2), (3, 170, 96, 4), (64, 16, 1, 5)])
+def test_gemm_tn(M, K, Nc, nb):
+    W = det_uniform((M, K), 200 + M)           # weights [M,K]
+    X = det_normalish((nb, K, Nc), 300 + K)
+    bias = det_uniform((nb, M), 400)
+    At = W.t().contiguous().to(dev)
+    C = torch.empty(nb, M, Nc, device=dev)
+    _lib.call("hpcs_gemm_tn", At, M, X.to(dev), Nc, K * Nc, 0, C, Nc, M * Nc, 0, M, Nc, K, nb, 1, bias.to(dev), 0)
+    want = torch.matmul(W.double(), X.double()) + bias.double().unsqueeze(-1)
+    torch.testing.assert_close(C.cpu().double(), want, rtol=1e-5, atol=1e-5 * float(want.abs().max()))
+    # data-grad form: At = W, reduces over M
+    G = det_normalish((nb, M, Nc), 500)
+    gX = torch.full((nb, K, Nc), 7.0, device=dev)
+    _lib.call("hpcs_gemm_tn", W.to(dev), K, G.to(dev), Nc, M * Nc, 0, gX, Nc, K * Nc, 0, K, Nc, M, nb, 1, None, 1)
+    want = torch.matmul(W.t().double(), G.double()) + 7.0
+    torch.testing.assert_close(gX.cpu().double(), want, rtol=1e-5, atol=1e-5 * float(want.abs().max()))
+
+
+def test_gemm_tn_inner_batch():
+    # walk a [B,K,3,N] tensor as 3B matrices of N columns with a per-(b,xyz) row bias
+    B, K, N, M = 2, 10, 96, 7
+    W = det_uniform((M, K), 1)
+    X = det_normalish((B, K, 3, N), 2)
+    bias = det_uniform((B * 3, M), 3)
+    C = torch.empty(B, M, 3, N, device=dev)
+    _lib.call("hpcs_gemm_tn", W.t().contiguous().to(dev), M, X.to(dev), 3 * N, K * 3 * N, N, C, 3 * N, M * 3 * N, N,
+              M, N, K, B, 3, bias.to(dev), 0)
+    want = torch.einsum("mk,bkxn->bmxn", W.double(), X.double()) + bias.double().view(B, 3, M).permute(0, 2, 1).unsqueeze(-1)
+    torch.testing.assert_close(C.cpu().double(), want, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("M,Kx,Nc,nb", [(42, 42, 5000, 3), (341, 63, 3 * 256, 2), (682, 682, 3 * 64, 2), (256, 1, 1, 6),
+                                        (3, 170, 96, 4)])
+def test_gemm_nt(M, Kx, Nc, nb):
+    G = det_normalish((nb, M, Nc), 600 + M)
+    X = det_normalish((nb, Kx, Nc), 700 + Kx)
+    nbytes = _lib.call("hpcs_gemm_nt_workspace", M, Kx, Nc, nb, 1)
+    ws = torch.empty(nbytes // 4 + 1, device=dev)
+    dW = torch.full((M, Kx), 3.0, device=dev)
+    _lib.call("hpcs_gemm_nt", G.to(dev), Nc, M * Nc, 0, X.to(dev), Nc, Kx * Nc, 0, M, Kx, Nc, nb, 1, dW, Kx, 1, ws, nbytes)
+    want = torch.einsum("bmc,bkc->mk", G.double(), X.double()) + 3.0
+    torch.testing.assert_close(dW.cpu().double(), want, rtol=1e-5, atol=2e-6 * float(want.abs().max()) * np.sqrt(Nc * nb))
