@@ -1,0 +1,405 @@
+// a7, a11, a15 + Poincare toolbox: row-wise kernels over [rows, E].
+//
+// Replaces expmap_1 / lambda_ / mobius_add / project / hyp_dist_o (hpcs/utils/poincare.py:16-136,
+// hpcs/distances/poincare.py:13-136), Artanh (hpcs/utils/math.py:61-78: clamp +-(1-1e-5), fp64 inside),
+// hyp_lca (hpcs/distances/lca.py:8-52) and HyperbolicDistance.compute_mat (hpcs/distances/poincare.py:144-176).
+//
+// Mapping: 8 lanes cooperate on one row (lane s handles elements s, s+8, ...; a 32-wide row is one 128-byte
+// segment per load), row reductions are three xor-shuffles.  These tensors are a few MB: the kernels are
+// launch/latency-scale, so the code favours exactness (fp64 for artanh and the LCA scalar algebra).
+//
+// hyp_lca: the reference's reflection construction is cancellation-bound in fp32 (2% median error at
+// scale 1e-3); we evaluate the same quantity in closed form: the geodesic through a,b is a
+// circle orthogonal to the unit sphere with centre c, c.a=(1+|a|^2)/2, c.b=(1+|b|^2)/2, and the projection of
+// the origin on it has norm m = |c| - sqrt(|c|^2-1), |c|^2 = |(1+aa)b-(1+bb)a|^2 / (4(aa*bb-ab^2)).
+#include "common.h"
+
+namespace {
+
+constexpr float MIN_NORM = 1e-15f;
+constexpr float BALL_EPS_F32 = 4e-3f;
+constexpr int SUB = 8;            // lanes per row
+constexpr int TPB = 256;
+constexpr int ROWS_PER_BLOCK = TPB / SUB;
+
+__device__ __forceinline__ float sub_sum(float v) {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    return v;
+}
+
+__device__ __forceinline__ double artanh_clamped(double x, double* dx_out) {
+    const double lim = 1.0 - 1e-5;
+    // the reference clamps the fp32 input, then evaluates in fp64
+    float xf = (float)x;
+    xf = fminf(fmaxf(xf, -1.f + 1e-5f), 1.f - 1e-5f);
+    (void)lim;
+    const double xc = (double)xf;
+    if (dx_out) *dx_out = 1.0 / (1.0 - xc * xc);
+    return 0.5 * (log1p(xc) - log1p(-xc));
+}
+
+#define ROW_PROLOGUE()                                                            \
+    const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x / SUB); \
+    const int s = threadIdx.x % SUB;                                              \
+    const bool live = row < rows;                                                 \
+    const int64_t base = (live ? row : 0) * E
+
+__global__ void expmap0_fwd_kernel(const float* __restrict__ u, int64_t rows, int E, float* __restrict__ out) {
+    ROW_PROLOGUE();
+    float ss = 0.f;
+    for (int i = s; i < E; i += SUB) { const float v = u[base + i]; ss += v * v; }
+    ss = sub_sum(ss);
+    const float un = fmaxf(sqrtf(ss), MIN_NORM);
+    const float sc = tanhf(fminf(un, 15.f)) / un;
+    if (live)
+        for (int i = s; i < E; i += SUB) out[base + i] = u[base + i] * sc;
+}
+
+__global__ void expmap0_bwd_kernel(const float* __restrict__ u, const float* __restrict__ g, int64_t rows, int E,
+                                   float* __restrict__ gu) {
+    ROW_PROLOGUE();
+    float ss = 0.f, ug = 0.f;
+    for (int i = s; i < E; i += SUB) { const float v = u[base + i]; ss += v * v; ug += v * g[base + i]; }
+    ss = sub_sum(ss);
+    ug = sub_sum(ug);
+    const float r = sqrtf(ss);
+    const float un = fmaxf(r, MIN_NORM);
+    const float t = tanhf(fminf(un, 15.f));
+    const float sc = t / un;
+    float coef = 0.f;
+    if (r > MIN_NORM) {
+        const float dt = un < 15.f ? (1.f - t * t) : 0.f;
+        coef = (dt * un - t) / (un * un) * ug / r;
+    }
+    if (live)
+        for (int i = s; i < E; i += SUB) gu[base + i] = sc * g[base + i] + coef * u[base + i];
+}
+
+// general exp-map at p: mobius_add(p, tanh(lambda_p*|u|/2) u/|u|)
+__global__ void expmap_fwd_kernel(const float* __restrict__ u, const float* __restrict__ p, int64_t rows, int E,
+                                  float* __restrict__ out) {
+    ROW_PROLOGUE();
+    float uu = 0.f, pp = 0.f, up = 0.f;
+    for (int i = s; i < E; i += SUB) {
+        const float a = u[base + i], b = p[base + i];
+        uu += a * a; pp += b * b; up += a * b;
+    }
+    uu = sub_sum(uu); pp = sub_sum(pp); up = sub_sum(up);
+    const float un = fmaxf(sqrtf(uu), MIN_NORM);
+    const float lam = 2.f / fmaxf(1.f - pp, MIN_NORM);
+    const float sc = tanhf(fminf(fmaxf(lam * un / 2.f, -15.f), 15.f)) / un;      // y = sc*u
+    const float y2 = sc * sc * uu, xy = sc * up, x2 = pp;
+    const float cx = 1.f + 2.f * xy + y2, cy = 1.f - x2;
+    const float den = fmaxf(1.f + 2.f * xy + x2 * y2, MIN_NORM);
+    if (live)
+        for (int i = s; i < E; i += SUB) out[base + i] = (cx * p[base + i] + cy * (sc * u[base + i])) / den;
+}
+
+__global__ void project_kernel(const float* __restrict__ x, int64_t rows, int E, float* __restrict__ out) {
+    ROW_PROLOGUE();
+    float ss = 0.f;
+    for (int i = s; i < E; i += SUB) { const float v = x[base + i]; ss += v * v; }
+    ss = sub_sum(ss);
+    const float n = fmaxf(sqrtf(ss), MIN_NORM);
+    const float maxn = 1.f - BALL_EPS_F32;
+    if (live)
+        for (int i = s; i < E; i += SUB) {
+            const float v = x[base + i];
+            out[base + i] = n > maxn ? v / n * maxn : v;
+        }
+}
+
+__global__ void mobius_add_kernel(const float* __restrict__ x, const float* __restrict__ y, int64_t rows, int E,
+                                  float* __restrict__ out) {
+    ROW_PROLOGUE();
+    float x2 = 0.f, y2 = 0.f, xy = 0.f;
+    for (int i = s; i < E; i += SUB) {
+        const float a = x[base + i], b = y[base + i];
+        x2 += a * a; y2 += b * b; xy += a * b;
+    }
+    x2 = sub_sum(x2); y2 = sub_sum(y2); xy = sub_sum(xy);
+    const float cx = 1.f + 2.f * xy + y2, cy = 1.f - x2;
+    const float den = fmaxf(1.f + 2.f * xy + x2 * y2, MIN_NORM);
+    if (live)
+        for (int i = s; i < E; i += SUB) out[base + i] = (cx * x[base + i] + cy * y[base + i]) / den;
+}
+
+__global__ void hyp_dist_o_kernel(const float* __restrict__ x, int64_t rows, int E, float* __restrict__ out) {
+    ROW_PROLOGUE();
+    float ss = 0.f;
+    for (int i = s; i < E; i += SUB) { const float v = x[base + i]; ss += v * v; }
+    ss = sub_sum(ss);
+    if (live && s == 0) out[row] = (float)(2.0 * artanh_clamped((double)sqrtf(ss), nullptr));
+}
+
+// ---- hyp_lca, general position ---------------------------------------------------------------------------
+struct LcaScalars { double aa, ab, bb, N, det, C2, m, d, dd_dm; };
+
+__device__ __forceinline__ LcaScalars lca_scalars(double aa, double ab, double bb) {
+    LcaScalars q;
+    q.aa = aa; q.ab = ab; q.bb = bb;
+    q.N = bb * (1 + aa) * (1 + aa) + aa * (1 + bb) * (1 + bb) - 2 * ab * (1 + aa) * (1 + bb);
+    q.det = aa * bb - ab * ab;
+    if (q.det <= 0.0 || q.N <= 0.0) {        // a, b, origin collinear: the geodesic is a diameter
+        q.C2 = INFINITY; q.m = 0.0; q.d = 0.0; q.dd_dm = 2.0;
+        return q;
+    }
+    q.C2 = fmax(q.N / (4.0 * q.det), 1.0);
+    const double C = sqrt(q.C2);
+    q.m = 1.0 / (C + sqrt(q.C2 - 1.0));
+    double dx;
+    q.d = 2.0 * artanh_clamped(q.m, &dx);
+    q.dd_dm = 2.0 * dx;
+    return q;
+}
+
+__global__ void hyp_lca_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t rows, int E,
+                                   float* __restrict__ dist, float* __restrict__ coord) {
+    ROW_PROLOGUE();
+    float aa = 0.f, ab = 0.f, bb = 0.f;
+    for (int i = s; i < E; i += SUB) {
+        const float x = a[base + i], y = b[base + i];
+        aa += x * x; ab += x * y; bb += y * y;
+    }
+    aa = sub_sum(aa); ab = sub_sum(ab); bb = sub_sum(bb);
+    const LcaScalars q = lca_scalars(aa, ab, bb);
+    if (!live) return;
+    if (s == 0 && dist) dist[row] = (float)q.d;
+    if (coord) {
+        // centre c = al*a + be*b ; proj = m * c/|c|
+        double al = 0.0, be = 0.0, cn = 1.0;
+        if (q.m > 0.0) {
+            al = (q.bb * (1 + q.aa) - q.ab * (1 + q.bb)) / (2.0 * q.det);
+            be = (q.aa * (1 + q.bb) - q.ab * (1 + q.aa)) / (2.0 * q.det);
+            cn = sqrt(q.C2);
+        }
+        const double f = q.m / cn;
+        for (int i = s; i < E; i += SUB) coord[base + i] = (float)(f * (al * a[base + i] + be * b[base + i]));
+    }
+}
+
+__global__ void hyp_lca_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ gdist,
+                                   int64_t rows, int E, float* __restrict__ ga, float* __restrict__ gb) {
+    ROW_PROLOGUE();
+    float aaf = 0.f, abf = 0.f, bbf = 0.f;
+    for (int i = s; i < E; i += SUB) {
+        const float x = a[base + i], y = b[base + i];
+        aaf += x * x; abf += x * y; bbf += y * y;
+    }
+    aaf = sub_sum(aaf); abf = sub_sum(abf); bbf = sub_sum(bbf);
+    const LcaScalars q = lca_scalars(aaf, abf, bbf);
+    if (!live) return;
+    double Faa = 0.0, Fab = 0.0, Fbb = 0.0;
+    if (q.m > 0.0 && q.C2 > 1.0) {
+        const double aa = q.aa, ab = q.ab, bb = q.bb;
+        // d = d(m), m = C - sqrt(C^2-1), C = sqrt(C2), C2 = N/(4 det)
+        const double C = sqrt(q.C2);
+        const double dm_dC = -q.m / sqrt(q.C2 - 1.0);
+        const double dC_dC2 = 0.5 / C;
+        const double g = (double)gdist[row] * q.dd_dm * dm_dC * dC_dC2;       // dL/dC2
+        const double N_aa = 2 * bb * (1 + aa) + (1 + bb) * (1 + bb) - 2 * ab * (1 + bb);
+        const double N_bb = (1 + aa) * (1 + aa) + 2 * aa * (1 + bb) - 2 * ab * (1 + aa);
+        const double N_ab = -2 * (1 + aa) * (1 + bb);
+        const double inv4det = 1.0 / (4.0 * q.det);
+        Faa = g * (N_aa * inv4det - q.C2 / q.det * bb);
+        Fbb = g * (N_bb * inv4det - q.C2 / q.det * aa);
+        Fab = g * (N_ab * inv4det + q.C2 / q.det * 2 * ab);
+    }
+    for (int i = s; i < E; i += SUB) {
+        const double x = a[base + i], y = b[base + i];
+        ga[base + i] = (float)(2 * Faa * x + Fab * y);
+        gb[base + i] = (float)(2 * Fbb * y + Fab * x);
+    }
+}
+
+// ---- a15 / a8 dense matrices (API completeness; the training path never builds them) ----------------------
+__global__ void hyperbolic_sim_mat_kernel(const float* __restrict__ x, const float* __restrict__ y, int M, int Mp, int E,
+                                          float* __restrict__ out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= Mp) return;
+    const float maxn = 1.f - BALL_EPS_F32;
+    float xx = 0.f, yy = 0.f;
+    for (int e = 0; e < E; ++e) { const float a = x[(int64_t)i * E + e], b = y[(int64_t)j * E + e]; xx += a * a; yy += b * b; }
+    const float nx = fmaxf(sqrtf(xx), MIN_NORM), ny = fmaxf(sqrtf(yy), MIN_NORM);
+    const float sx = nx > maxn ? maxn / nx : 1.f, sy = ny > maxn ? maxn / ny : 1.f;
+    float d2 = 0.f;
+    for (int e = 0; e < E; ++e) { const float df = x[(int64_t)i * E + e] * sx - y[(int64_t)j * E + e] * sy; d2 += df * df; }
+    const float ax = 1.f - xx * sx * sx, ay = 1.f - yy * sy * sy;
+    const float dxy = 1.f + 2.f * (d2 / (ax * ay));
+    out[(int64_t)i * Mp + j] = expf(-acoshf(dxy));
+}
+
+__global__ void cosine_mat_kernel(const float* __restrict__ xn, const float* __restrict__ yn, int M, int Mp, int E,
+                                  float* __restrict__ out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= Mp) return;
+    float d = 0.f;
+    for (int e = 0; e < E; ++e) d = __builtin_fmaf(xn[(int64_t)i * E + e], yn[(int64_t)j * E + e], d);
+    out[(int64_t)i * Mp + j] = 0.5f * (1.f + d);
+}
+
+// ---- l2 row normalisation (PML BaseDistance.maybe_normalize == F.normalize(p=2, dim=1, eps=1e-12)) --------
+__global__ void l2_rows_fwd_kernel(const float* __restrict__ x, int64_t rows, int E, float* __restrict__ xn,
+                                   float* __restrict__ inv_norm) {
+    ROW_PROLOGUE();
+    float ss = 0.f;
+    for (int i = s; i < E; i += SUB) { const float v = x[base + i]; ss += v * v; }
+    ss = sub_sum(ss);
+    const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+    if (!live) return;
+    for (int i = s; i < E; i += SUB) xn[base + i] = x[base + i] * inv;
+    if (s == 0 && inv_norm) inv_norm[row] = inv;
+}
+
+__global__ void l2_rows_bwd_kernel(const float* __restrict__ xn, const float* __restrict__ inv_norm,
+                                   const float* __restrict__ gxn, int64_t rows, int E, float* __restrict__ gx, int accumulate) {
+    ROW_PROLOGUE();
+    float dot = 0.f;
+    for (int i = s; i < E; i += SUB) dot += xn[base + i] * gxn[base + i];
+    dot = sub_sum(dot);
+    if (!live) return;
+    const float inv = inv_norm[row];
+    for (int i = s; i < E; i += SUB) {
+        const float v = (gxn[base + i] - xn[base + i] * dot) * inv;
+        gx[base + i] = accumulate ? gx[base + i] + v : v;
+    }
+}
+
+__global__ void colsum_kernel(const float* __restrict__ x, int64_t rows, int E, double* __restrict__ colsum) {
+    // grid.x = E columns chunks of 64 lanes; each block reduces a slab of rows for 64 columns
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.y * 1024;
+    const int64_t r1 = r0 + 1024 < rows ? r0 + 1024 : rows;
+    double acc = 0.0;
+    if (e < E)
+        for (int64_t r = r0 + w; r < r1; r += nw) acc += (double)x[r * E + e];
+    __shared__ double sh[4][64];
+    sh[w][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (w == 0 && e < E) {
+        double t = 0.0;
+        for (int i = 0; i < nw; ++i) t += sh[i][threadIdx.x & 63];
+        atomicAdd(colsum + e, t);
+    }
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+#define ROW_GRID(rows) dim3((unsigned)hpcs_cdiv((rows), ROWS_PER_BLOCK)), dim3(TPB), 0, ST
+#define ROW_ARGS_OK(rows, E) ((rows) >= 0 && (E) > 0)
+
+extern "C" int hpcs_expmap0_fwd(const float* u, int64_t rows, int E, float* out, hpcs_stream_t stream) {
+    if (!u || !out) return HPCS_ERR_NULL;
+    if (!ROW_ARGS_OK(rows, E)) return HPCS_ERR_SHAPE;
+    if (rows == 0) return HPCS_OK;
+    hipLaunchKernelGGL(expmap0_fwd_kernel, ROW_GRID(rows), u, rows, E, out);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+extern "C" int hpcs_expmap0_bwd(const float* u, const float* gout, int64_t rows, int E, float* gu, hpcs_stream_t stream) {
+    if (!u || !gout || !gu) return HPCS_ERR_NULL;
+    if (!ROW_ARGS_OK(rows, E)) return HPCS_ERR_SHAPE;
+    if (rows == 0) return HPCS_OK;
+    hipLaunchKernelGGL(expmap0_bwd_kernel, ROW_GRID(rows), u, gout, rows, E, gu);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+extern "C" int hpcs_expmap_fwd(const float* u, const float* p, int64_t rows, int E, float* out, hpcs_stream_t stream) {
+    if (!u || !p || !out) return HPCS_ERR_NULL;
+    if (!ROW_ARGS_OK(rows, E)) return HPCS_ERR_SHAPE;
+    if (rows == 0) return HPCS_OK;
+    hipLaunchKernelGGL(expmap_fwd_kernel, ROW_GRID(rows), u, p, rows, E, out);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+extern "C" int hpcs_project(const float* x, int64_t rows, int E, float* out, hpcs_stream_t stream) {
+    if (!x || !out) return HPCS_ERR_NULL;
+    if (!ROW_ARGS_OK(rows, E)) return HPCS_ERR_SHAPE;
+    if (rows == 0) return HPCS_OK;
+    hipLaunchKernelGGL(project_kernel, ROW_GRID(rows), x, rows, E, out);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+extern "C" int hpcs_mobius_add(const float* x, const float* y, int64_t rows, int E, float* out, hpcs_stream_t stream) {
+    if (!x || !y || !out) return HPCS_ERR_NULL;
+    if (!ROW_ARGS_OK(rows, E)) return HPCS_ERR_SHAPE;
+    if (rows == 0) return HPCS_OK;
+    hipLaunchKernelGGL(mobius_add_kernel, ROW_GRID(rows), x, y, rows, E, out);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+extern "C" int hpcs_hyp_dist_o(const float* x, int64_t rows, int E, float* out, hpcs_stream_t stream) {
+    if (!x || !out) return HPCS_ERR_NULL;
+    if (!ROW_ARGS_OK(rows, E)) return HPCS_ERR_SHAPE;
+    if (rows == 0) return HPCS_OK;
+    hipLaunchKernelGGL(hyp_dist_o_kernel, ROW_GRID(rows), x, rows, E, out);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+extern "C" int hpcs_hyp_lca_fwd(const float* a, const float* b, int64_t rows, int E, float* dist, float* coord,
+                                hpcs_stream_t stream) {
+    if (!a || !b || (!dist && !coord)) return HPCS_ERR_NULL;
+    if (!ROW_ARGS_OK(rows, E)) return HPCS_ERR_SHAPE;
+    if (rows == 0) return HPCS_OK;
+    hipLaunchKernelGGL(hyp_lca_fwd_kernel, ROW_GRID(rows), a, b, rows, E, dist, coord);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+extern "C" int hpcs_hyp_lca_bwd(const float* a, const float* b, const float* gdist, int64_t rows, int E, float* ga,
+                                float* gb, hpcs_stream_t stream) {
+    if (!a || !b || !gdist || !ga || !gb) return HPCS_ERR_NULL;
+    if (!ROW_ARGS_OK(rows, E)) return HPCS_ERR_SHAPE;
+    if (rows == 0) return HPCS_OK;
+    hipLaunchKernelGGL(hyp_lca_bwd_kernel, ROW_GRID(rows), a, b, gdist, rows, E, ga, gb);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+extern "C" int hpcs_hyperbolic_sim_mat(const float* x, const float* y, int M, int Mp, int E, float* out,
+                                       hpcs_stream_t stream) {
+    if (!x || !y || !out) return HPCS_ERR_NULL;
+    if (M < 0 || Mp < 0 || E <= 0 || M > 65535) return HPCS_ERR_SHAPE;
+    if (M == 0 || Mp == 0) return HPCS_OK;
+    hipLaunchKernelGGL(hyperbolic_sim_mat_kernel, dim3(hpcs_cdiv(Mp, 256), M), dim3(256), 0, ST, x, y, M, Mp, E, out);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+extern "C" int hpcs_cosine_mat(const float* xn, const float* yn, int M, int Mp, int E, float* out, hpcs_stream_t stream) {
+    if (!xn || !yn || !out) return HPCS_ERR_NULL;
+    if (M < 0 || Mp < 0 || E <= 0 || M > 65535) return HPCS_ERR_SHAPE;
+    if (M == 0 || Mp == 0) return HPCS_OK;
+    hipLaunchKernelGGL(cosine_mat_kernel, dim3(hpcs_cdiv(Mp, 256), M), dim3(256), 0, ST, xn, yn, M, Mp, E, out);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+extern "C" int hpcs_l2_rows_fwd(const float* x, int64_t rows, int E, float* xn, float* inv_norm, hpcs_stream_t stream) {
+    if (!x || !xn) return HPCS_ERR_NULL;
+    if (!ROW_ARGS_OK(rows, E)) return HPCS_ERR_SHAPE;
+    if (rows == 0) return HPCS_OK;
+    hipLaunchKernelGGL(l2_rows_fwd_kernel, ROW_GRID(rows), x, rows, E, xn, inv_norm);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+extern "C" int hpcs_l2_rows_bwd(const float* xn, const float* inv_norm, const float* gxn, int64_t rows, int E, float* gx,
+                                int accumulate, hpcs_stream_t stream) {
+    if (!xn || !inv_norm || !gxn || !gx) return HPCS_ERR_NULL;
+    if (!ROW_ARGS_OK(rows, E)) return HPCS_ERR_SHAPE;
+    if (rows == 0) return HPCS_OK;
+    hipLaunchKernelGGL(l2_rows_bwd_kernel, ROW_GRID(rows), xn, inv_norm, gxn, rows, E, gx, accumulate);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+extern "C" int hpcs_colsum(const float* xn, int64_t rows, int E, double* colsum, hpcs_stream_t stream) {
+    if (!xn || !colsum) return HPCS_ERR_NULL;
+    if (!ROW_ARGS_OK(rows, E)) return HPCS_ERR_SHAPE;
+    if (hipMemsetAsync(colsum, 0, sizeof(double) * E, ST) != hipSuccess) return HPCS_ERR_HIP;
+    if (rows == 0) return HPCS_OK;
+    hipLaunchKernelGGL(colsum_kernel, dim3(hpcs_cdiv(E, 64), hpcs_cdiv(rows, 1024)), dim3(256), 0, ST, xn, rows, E, colsum);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}

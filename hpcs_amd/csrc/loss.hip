@@ -1,0 +1,585 @@
+// a8-a14: class-balanced triplet sampling, margin filter with stable compaction, matrix-free HypHC loss,
+// CosFace and triplet-margin losses -- forward and backward.
+//
+// Replaces get_balanced_random_triplet_indices (hpcs/miner/loss_and_miner_utils.py:7-75),
+// RandomTripletMarginMiner.mine (hpcs/miner/triplet_margin_miner.py:13-38),
+// MetricHyperbolicLoss.compute_hyp (hpcs/loss/ultrametric_loss.py:57-93), PML CosFaceLoss (algorithm
+// mirrored in hpcs/loss/hierarchical_cosface_loss.py:57-87) and TripletMarginLoss
+// (hpcs/miner/triplet_margin_loss.py:34-65).
+//
+// Data layout: xn [M,E] = L2-normalised embedding rows (4 MB at M=32768,E=32: L2-resident); triplets are three
+// int64 index arrays.  The reference's two (B*N)^2 cosine matrices (4.3 GB each) are never built: every
+// similarity the path consumes is a gathered row dot, and HypHC's LCA distance for two points of equal norm s
+// depends only on that similarity:  d = 2 artanh(m), m = 1/(C+sqrt(C^2-1)), C = (1+s^2)/(2 s sqrt(w)), w=(1+cos)/2.
+// 8 lanes cooperate on one triplet (a 32-float row = one 128-byte segment per gather).
+#include "common.h"
+
+namespace {
+
+constexpr int SUB = 8;
+constexpr int TPB = 256;
+constexpr int TRIP_PER_PASS = TPB / SUB;   // 32
+constexpr int CHUNK = 2048;                // triplets per workgroup in the filter
+
+__device__ __forceinline__ float sub_sum(float v) {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    return v;
+}
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ uint64_t bounded(uint64_t r, uint64_t n) { return __umul64hi(r, n); }
+
+// ---------------------------------------------------------------------------------------------- class index
+__global__ void hist_kernel(const int64_t* __restrict__ labels, int M, int C, int32_t* __restrict__ counts) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const int64_t l = labels[i];
+    if (l >= 0 && l < C) atomicAdd(counts + l, 1);
+}
+__global__ void offsets_kernel(const int32_t* __restrict__ counts, int C, int32_t* __restrict__ offsets) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int acc = 0;
+        for (int c = 0; c < C; ++c) { offsets[c] = acc; acc += counts[c]; }
+        offsets[C] = acc;
+    }
+}
+// one workgroup per class: members in ascending index order (stable)
+__global__ void class_fill_kernel(const int64_t* __restrict__ labels, int M, const int32_t* __restrict__ offsets,
+                                  int32_t* __restrict__ order) {
+    __shared__ int wave_cnt[TPB / 64];
+    __shared__ int base_sh;
+    const int c = blockIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) base_sh = offsets[c];
+    __syncthreads();
+    for (int i0 = 0; i0 < M; i0 += TPB) {
+        const int i = i0 + threadIdx.x;
+        const bool mine = i < M && labels[i] == c;
+        const unsigned long long bal = __ballot(mine);
+        if (lane == 0) wave_cnt[w] = __popcll(bal);
+        __syncthreads();
+        int before = 0;
+        for (int j = 0; j < w; ++j) before += wave_cnt[j];
+        int tot = 0;
+        for (int j = 0; j < TPB / 64; ++j) tot += wave_cnt[j];
+        const int base = base_sh;
+        if (mine) order[base + before + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+        __syncthreads();
+        if (threadIdx.x == 0) base_sh = base + tot;
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- sampler
+__global__ void sample_triplets_kernel(const int32_t* __restrict__ order, const int32_t* __restrict__ offsets,
+                                       const int64_t* __restrict__ cls_toff, const int32_t* __restrict__ cls_k, int C, int M,
+                                       int64_t T, const int64_t* __restrict__ draws_pos, const int64_t* __restrict__ draws_neg,
+                                       uint64_t seed, int64_t* __restrict__ a, int64_t* __restrict__ p, int64_t* __restrict__ n) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    int lo = 0, hi = C;                       // largest c with cls_toff[c] <= t (classes with k=0 have empty ranges)
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (cls_toff[mid] <= t) lo = mid; else hi = mid;
+    }
+    while (lo + 1 < C && cls_toff[lo + 1] <= t) ++lo;
+    const int c = lo;
+    const int k = cls_k[c];
+    const int64_t local = t - cls_toff[c];
+    const int rank = (int)(local / k);
+    const int off = offsets[c];
+    const int n_a = offsets[c + 1] - off;
+    const int32_t* mem = order + off;
+    const int64_t rp = draws_pos ? draws_pos[t] : (int64_t)bounded(mix64(seed ^ mix64(2 * (uint64_t)t)), (uint64_t)(n_a - 1));
+    const int64_t rn = draws_neg ? draws_neg[t] : (int64_t)bounded(mix64(seed ^ mix64(2 * (uint64_t)t + 1)), (uint64_t)(M - n_a));
+    a[t] = mem[rank];
+    p[t] = mem[rp + (rp >= rank ? 1 : 0)];
+    // rn-th point NOT in the class, in ascending index order: rn + #{i : mem[i]-i <= rn}
+    int l2 = 0, h2 = n_a;
+    while (l2 < h2) {
+        const int mid = (l2 + h2) >> 1;
+        if ((int64_t)mem[mid] - mid <= rn) l2 = mid + 1; else h2 = mid;
+    }
+    n[t] = rn + l2;
+}
+
+// ---------------------------------------------------------------------------------------------- filter
+__device__ __forceinline__ bool keep_rule(float tm, float margin, int kind) {
+    if (kind == HPCS_TRIPLETS_EASY) return tm > margin;
+    bool k = tm <= margin;
+    if (kind == HPCS_TRIPLETS_HARD) k = k && (tm <= 0.f);
+    else if (kind == HPCS_TRIPLETS_SEMIHARD) k = k && (tm > 0.f);
+    return k;
+}
+
+__global__ void filter_flag_kernel(const float* __restrict__ xn, int E, const int64_t* __restrict__ a,
+                                   const int64_t* __restrict__ p, const int64_t* __restrict__ n, int64_t T, float margin,
+                                   int kind, uint8_t* __restrict__ flags, int32_t* __restrict__ block_cnt) {
+    __shared__ int cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    const int s = threadIdx.x % SUB, g = threadIdx.x / SUB;
+    const int64_t t0 = (int64_t)blockIdx.x * CHUNK;
+    int local = 0;
+    for (int pass = 0; pass < CHUNK / TRIP_PER_PASS; ++pass) {
+        const int64_t t = t0 + (int64_t)pass * TRIP_PER_PASS + g;
+        const bool live = t < T;
+        const int64_t ia = live ? a[t] : 0, ip = live ? p[t] : 0, in = live ? n[t] : 0;
+        float dp = 0.f, dn = 0.f;
+        for (int e = s; e < E; e += SUB) {
+            const float av = xn[ia * E + e];
+            dp += av * xn[ip * E + e];
+            dn += av * xn[in * E + e];
+        }
+        dp = sub_sum(dp);
+        dn = sub_sum(dn);
+        const float tm = 0.5f * (1.f + dp) - 0.5f * (1.f + dn);
+        const bool keep = live && keep_rule(tm, margin, kind);
+        if (live && s == 0) {
+            flags[t] = keep ? 1 : 0;
+            local += keep ? 1 : 0;
+        }
+    }
+    if (local) atomicAdd(&cnt, local);
+    __syncthreads();
+    if (threadIdx.x == 0) block_cnt[blockIdx.x] = cnt;
+}
+
+__global__ void filter_scan_kernel(const int32_t* __restrict__ block_cnt, int nblocks, int64_t* __restrict__ block_off,
+                                   int64_t* __restrict__ count) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int64_t acc = 0;
+        for (int i = 0; i < nblocks; ++i) { block_off[i] = acc; acc += block_cnt[i]; }
+        *count = acc;
+    }
+}
+
+__global__ void filter_scatter_kernel(const uint8_t* __restrict__ flags, const int64_t* __restrict__ block_off,
+                                      const int64_t* __restrict__ a, const int64_t* __restrict__ p, const int64_t* __restrict__ n,
+                                      int64_t T, int64_t* __restrict__ ao, int64_t* __restrict__ po, int64_t* __restrict__ no) {
+    __shared__ int wsum[TPB / 64];
+    constexpr int PER = CHUNK / TPB;      // 8 consecutive triplets per thread (keeps order)
+    const int64_t t0 = (int64_t)blockIdx.x * CHUNK + (int64_t)threadIdx.x * PER;
+    int f[PER], mine = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        f[i] = (t0 + i < T) ? flags[t0 + i] : 0;
+        mine += f[i];
+    }
+    // inclusive scan of `mine` across the workgroup
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    int before = 0;
+    for (int j = 0; j < w; ++j) before += wsum[j];
+    int64_t dst = block_off[blockIdx.x] + before + incl - mine;
+#pragma unroll
+    for (int i = 0; i < PER; ++i)
+        if (f[i]) {
+            ao[dst] = a[t0 + i];
+            po[dst] = p[t0 + i];
+            no[dst] = n[t0 + i];
+            ++dst;
+        }
+}
+
+// ---------------------------------------------------------------------------------------------- HypHC
+struct LcaW { double d, dd_dw, dd_ds; };
+
+// d(s, w) and its partials; w = 0.5*(1+cos) in [0,1], s in [1e-4,1]
+__device__ __forceinline__ LcaW lca_of_sim(double s, double w) {
+    LcaW r;
+    const double wc = fmax(w, 1e-12);
+    const double sq = sqrt(wc);
+    const double C = fmax((1.0 + s * s) / (2.0 * s * sq), 1.0);
+    const double root = sqrt(fmax(C * C - 1.0, 0.0));
+    const double m = 1.0 / (C + root);
+    float mf = (float)m;                                      // Artanh clamps the fp32 value
+    mf = fminf(mf, 1.f - 1e-5f);
+    const double mc = (double)mf;
+    r.d = log1p(mc) - log1p(-mc);                             // 2*artanh
+    const double dd_dm = 2.0 / (1.0 - mc * mc);
+    const double dm_dC = -m / fmax(root, 1e-12);
+    const double g = dd_dm * dm_dC;
+    r.dd_dw = g * (-C / (2.0 * wc));
+    r.dd_ds = g * (C * (s * s - 1.0) / (s * (1.0 + s * s)));
+    return r;
+}
+
+__device__ __forceinline__ void triplet_sims(const float* __restrict__ xn, int E, int64_t ia, int64_t ip, int64_t in, int s,
+                                             float& wij, float& wik, float& wjk) {
+    float d1 = 0.f, d2 = 0.f, d3 = 0.f;
+    for (int e = s; e < E; e += SUB) {
+        const float av = xn[ia * E + e], pv = xn[ip * E + e], nv = xn[in * E + e];
+        d1 += av * pv;
+        d2 += av * nv;
+        d3 += pv * nv;
+    }
+    wij = 0.5f * (1.f + sub_sum(d1));
+    wik = 0.5f * (1.f + sub_sum(d2));
+    wjk = 0.5f * (1.f + sub_sum(d3));
+}
+
+__global__ void hyphc_fwd_kernel(const float* __restrict__ xn, int E, const int64_t* __restrict__ a, const int64_t* __restrict__ p,
+                                 const int64_t* __restrict__ n, const int64_t* __restrict__ count, int64_t T_cap,
+                                 const float* __restrict__ scale, float temperature, double* __restrict__ loss_sum) {
+    __shared__ double red[16];
+    const int64_t T = *count < T_cap ? *count : T_cap;
+    const double sc = (double)fminf(fmaxf(*scale, 1e-4f), 1.f);
+    const int s = threadIdx.x % SUB, g = threadIdx.x / SUB;
+    double acc = 0.0;
+    for (int64_t t = (int64_t)blockIdx.x * TRIP_PER_PASS + g; t - g < T; t += (int64_t)gridDim.x * TRIP_PER_PASS) {
+        const bool live = t < T;
+        const int64_t ia = live ? a[t] : 0, ip = live ? p[t] : 0, in = live ? n[t] : 0;
+        float w[3];
+        triplet_sims(xn, E, ia, ip, in, s, w[0], w[1], w[2]);
+        if (live && s == 0) {
+            double d[3], mx = -1e300;
+            for (int i = 0; i < 3; ++i) { d[i] = lca_of_sim(sc, (double)w[i]).d / (double)temperature; mx = fmax(mx, d[i]); }
+            double den = 0.0, num = 0.0, sw = 0.0;
+            for (int i = 0; i < 3; ++i) { const double ex = exp(d[i] - mx); den += ex; num += ex * (double)w[i]; sw += (double)w[i]; }
+            acc += sw - num / den;
+        }
+    }
+    const double tot = hpcs_block_sum<double>(acc, red);
+    if (threadIdx.x == 0 && tot != 0.0) atomicAdd(loss_sum, tot);
+}
+
+__global__ void hyphc_bwd_kernel(const float* __restrict__ xn, int E, const int64_t* __restrict__ a, const int64_t* __restrict__ p,
+                                 const int64_t* __restrict__ n, const int64_t* __restrict__ count, int64_t T_cap,
+                                 const float* __restrict__ scale, float temperature, const float* __restrict__ gloss,
+                                 float* __restrict__ gxn, double* __restrict__ gscale) {
+    __shared__ double red[16];
+    const int64_t T = *count < T_cap ? *count : T_cap;
+    const float sraw = *scale;
+    const double sc = (double)fminf(fmaxf(sraw, 1e-4f), 1.f);
+    const bool s_live = sraw >= 1e-4f && sraw <= 1.f;          // torch.clamp passes the gradient inside the range
+    const double up = T > 0 ? (double)(*gloss) / (double)T : 0.0;
+    const int s = threadIdx.x % SUB, g = threadIdx.x / SUB;
+    double gs_acc = 0.0;
+    for (int64_t t = (int64_t)blockIdx.x * TRIP_PER_PASS + g; t - g < T; t += (int64_t)gridDim.x * TRIP_PER_PASS) {
+        const bool live = t < T;
+        const int64_t ia = live ? a[t] : 0, ip = live ? p[t] : 0, in = live ? n[t] : 0;
+        float w[3];
+        triplet_sims(xn, E, ia, ip, in, s, w[0], w[1], w[2]);
+        float gw[3] = {0.f, 0.f, 0.f};
+        if (live) {          // every lane of the sub-group evaluates the scalars (cheaper than a broadcast)
+            LcaW L[3];
+            double d[3], mx = -1e300;
+            for (int i = 0; i < 3; ++i) { L[i] = lca_of_sim(sc, (double)w[i]); d[i] = L[i].d / (double)temperature; mx = fmax(mx, d[i]); }
+            double ex[3], den = 0.0, num = 0.0;
+            for (int i = 0; i < 3; ++i) { ex[i] = exp(d[i] - mx); den += ex[i]; num += ex[i] * (double)w[i]; }
+            const double wbar = num / den;
+            for (int i = 0; i < 3; ++i) {
+                const double sm = ex[i] / den;
+                const double gd = -(sm * ((double)w[i] - wbar)) / (double)temperature;   // d loss_t / d d_i
+                gw[i] = (float)(up * ((1.0 - sm) + gd * L[i].dd_dw));
+                if (s == 0 && s_live) gs_acc += up * gd * L[i].dd_ds;
+            }
+            // w = 0.5*(1+dot): d/d xn rows
+            const float c0 = 0.5f * gw[0], c1 = 0.5f * gw[1], c2 = 0.5f * gw[2];
+            for (int e = s; e < E; e += SUB) {
+                const float av = xn[ia * E + e], pv = xn[ip * E + e], nv = xn[in * E + e];
+                atomicAdd(gxn + ia * E + e, c0 * pv + c1 * nv);
+                atomicAdd(gxn + ip * E + e, c0 * av + c2 * nv);
+                atomicAdd(gxn + in * E + e, c1 * av + c2 * pv);
+            }
+        }
+    }
+    const double tot = hpcs_block_sum<double>(gs_acc, red);
+    if (threadIdx.x == 0 && tot != 0.0) atomicAdd(gscale, tot);
+}
+
+// ---------------------------------------------------------------------------------------------- CosFace
+__global__ void cosface_fwd_kernel(const float* __restrict__ xn, const float* __restrict__ wn, const int64_t* __restrict__ labels,
+                                   int M, int E, int C, float margin, float scale, float* __restrict__ logits,
+                                   float* __restrict__ loss_rows) {
+    extern __shared__ float wsh[];          // [C][E]
+    for (int i = threadIdx.x; i < C * E; i += blockDim.x) wsh[i] = wn[i];
+    __syncthreads();
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= M) return;
+    const int lab = (int)labels[row];
+    const float* xr = xn + (int64_t)row * E;
+    float* lr = logits + (int64_t)row * C;
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) {
+        float cs = 0.f;
+        for (int e = 0; e < E; ++e) cs = __builtin_fmaf(xr[e], wsh[c * E + e], cs);
+        if (c == lab) {
+            const float diff = (cs - margin) - cs;
+            cs = cs + diff;
+        }
+        const float lg = cs * scale;
+        lr[c] = lg;
+        mx = fmaxf(mx, lg);
+    }
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(lr[c] - mx);
+    loss_rows[row] = (mx + logf(se)) - lr[lab];
+}
+
+// grad wrt xn rows; one thread per row
+__global__ void cosface_bwd_x_kernel(const float* __restrict__ wn, const int64_t* __restrict__ labels,
+                                     const float* __restrict__ logits, int M, int E, int C, float scale,
+                                     const float* __restrict__ gloss, float* __restrict__ gxn) {
+    extern __shared__ float wsh[];
+    const float gmean = *gloss / (float)M;
+    for (int i = threadIdx.x; i < C * E; i += blockDim.x) wsh[i] = wn[i];
+    __syncthreads();
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= M) return;
+    const int lab = (int)labels[row];
+    const float* lr = logits + (int64_t)row * C;
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, lr[c]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(lr[c] - mx);
+    const float inv = 1.f / se;
+    for (int e = 0; e < E; ++e) {
+        float acc = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float dl = (expf(lr[c] - mx) * inv - (c == lab ? 1.f : 0.f)) * gmean * scale;
+            acc = __builtin_fmaf(dl, wsh[c * E + e], acc);
+        }
+        gxn[(int64_t)row * E + e] += acc;
+    }
+}
+
+// grad wrt wn [C,E]; one workgroup per class, threads over rows
+__global__ void cosface_bwd_w_kernel(const float* __restrict__ xn, const int64_t* __restrict__ labels,
+                                     const float* __restrict__ logits, const float* __restrict__ loss_rows, int M, int E,
+                                     int C, float scale, const float* __restrict__ gloss, float* __restrict__ gwn) {
+    __shared__ float red[16];
+    const float gmean = *gloss / (float)M;
+    const int c = blockIdx.x;
+    for (int e = 0; e < E; ++e) {
+        float acc = 0.f;
+        for (int row = threadIdx.x; row < M; row += blockDim.x) {
+            const int lab = (int)labels[row];
+            const float* lr = logits + (int64_t)row * C;
+            const float lse = loss_rows[row] + lr[lab];
+            const float dl = (expf(lr[c] - lse) - (c == lab ? 1.f : 0.f)) * gmean * scale;
+            acc = __builtin_fmaf(dl, xn[(int64_t)row * E + e], acc);
+        }
+        const float tot = hpcs_block_sum<float>(acc, red);
+        if (threadIdx.x == 0) gwn[(int64_t)c * E + e] = tot;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- triplet margin
+__global__ void triplet_margin_fwd_kernel(const float* __restrict__ xn, int E, const int64_t* __restrict__ a,
+                                          const int64_t* __restrict__ p, const int64_t* __restrict__ n,
+                                          const int64_t* __restrict__ count, int64_t T_cap, float margin,
+                                          double* __restrict__ sum_nnz) {
+    __shared__ double red[16];
+    const int64_t T = *count < T_cap ? *count : T_cap;
+    const int s = threadIdx.x % SUB, g = threadIdx.x / SUB;
+    double acc = 0.0, nz = 0.0;
+    for (int64_t t = (int64_t)blockIdx.x * TRIP_PER_PASS + g; t - g < T; t += (int64_t)gridDim.x * TRIP_PER_PASS) {
+        const bool live = t < T;
+        const int64_t ia = live ? a[t] : 0, ip = live ? p[t] : 0, in = live ? n[t] : 0;
+        float wij, wik, wjk;
+        triplet_sims(xn, E, ia, ip, in, s, wij, wik, wjk);
+        const float viol = (wik - wij) + margin;
+        if (live && s == 0 && viol > 0.f) { acc += (double)viol; nz += 1.0; }
+    }
+    const double t1 = hpcs_block_sum<double>(acc, red);
+    const double t2 = hpcs_block_sum<double>(nz, red);
+    if (threadIdx.x == 0 && t2 != 0.0) { atomicAdd(sum_nnz, t1); atomicAdd(sum_nnz + 1, t2); }
+}
+
+__global__ void triplet_margin_bwd_kernel(const float* __restrict__ xn, int E, const int64_t* __restrict__ a,
+                                          const int64_t* __restrict__ p, const int64_t* __restrict__ n,
+                                          const int64_t* __restrict__ count, int64_t T_cap, float margin,
+                                          const double* __restrict__ sum_nnz, const float* __restrict__ gloss,
+                                          float* __restrict__ gxn) {
+    const int64_t T = *count < T_cap ? *count : T_cap;
+    const double nnz = sum_nnz[1];
+    if (nnz <= 0.0) return;
+    const float up = 0.5f * (float)((double)(*gloss) / nnz);
+    const int s = threadIdx.x % SUB, g = threadIdx.x / SUB;
+    for (int64_t t = (int64_t)blockIdx.x * TRIP_PER_PASS + g; t - g < T; t += (int64_t)gridDim.x * TRIP_PER_PASS) {
+        const bool live = t < T;
+        const int64_t ia = live ? a[t] : 0, ip = live ? p[t] : 0, in = live ? n[t] : 0;
+        float wij, wik, wjk;
+        triplet_sims(xn, E, ia, ip, in, s, wij, wik, wjk);
+        const float viol = (wik - wij) + margin;
+        if (live && viol > 0.f)
+            for (int e = s; e < E; e += SUB) {
+                const float av = xn[ia * E + e], pv = xn[ip * E + e], nv = xn[in * E + e];
+                atomicAdd(gxn + ia * E + e, up * (nv - pv));
+                atomicAdd(gxn + in * E + e, up * av);
+                atomicAdd(gxn + ip * E + e, -up * av);
+            }
+    }
+}
+
+inline unsigned trip_grid(int64_t T_cap) {
+    int64_t b = (T_cap + TRIP_PER_PASS - 1) / TRIP_PER_PASS;
+    if (b > 8192) b = 8192;          // grid-stride the rest
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int hpcs_class_index(const int64_t* labels, int M, int C, int32_t* order, int32_t* offsets, int32_t* counts_ws,
+                                hpcs_stream_t stream) {
+    if (!labels || !order || !offsets || !counts_ws) return HPCS_ERR_NULL;
+    if (M < 0 || C <= 0) return HPCS_ERR_SHAPE;
+    if (hipMemsetAsync(counts_ws, 0, sizeof(int32_t) * C, ST) != hipSuccess) return HPCS_ERR_HIP;
+    if (M > 0) {
+        hipLaunchKernelGGL(hist_kernel, dim3(hpcs_cdiv(M, TPB)), dim3(TPB), 0, ST, labels, M, C, counts_ws);
+        HPCS_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(offsets_kernel, dim3(1), dim3(64), 0, ST, counts_ws, C, offsets);
+    HPCS_CHECK_LAUNCH();
+    if (M > 0) {
+        hipLaunchKernelGGL(class_fill_kernel, dim3(C), dim3(TPB), 0, ST, labels, M, offsets, order);
+        HPCS_CHECK_LAUNCH();
+    }
+    return HPCS_OK;
+}
+
+extern "C" int hpcs_sample_triplets(const int32_t* order, const int32_t* offsets, const int64_t* cls_toff,
+                                    const int32_t* cls_k, int C, int M, int64_t T, const int64_t* draws_pos,
+                                    const int64_t* draws_neg, uint64_t seed, int64_t* a, int64_t* p, int64_t* n,
+                                    hpcs_stream_t stream) {
+    if (!order || !offsets || !cls_toff || !cls_k || !a || !p || !n) return HPCS_ERR_NULL;
+    if ((draws_pos == nullptr) != (draws_neg == nullptr)) return HPCS_ERR_NULL;
+    if (C <= 0 || M <= 0 || T < 0) return HPCS_ERR_SHAPE;
+    if (T == 0) return HPCS_OK;
+    hipLaunchKernelGGL(sample_triplets_kernel, dim3(hpcs_cdiv(T, TPB)), dim3(TPB), 0, ST, order, offsets, cls_toff, cls_k, C, M,
+                       T, draws_pos, draws_neg, seed, a, p, n);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
+extern "C" size_t hpcs_triplet_filter_workspace(int64_t T) {
+    if (T <= 0) return 64;
+    const int64_t nb = (T + CHUNK - 1) / CHUNK;
+    return (size_t)(((T + 15) / 16) * 16 + nb * sizeof(int32_t) + 16 + nb * sizeof(int64_t) + 64);
+}
+
+extern "C" int hpcs_triplet_filter(const float* xn, int E, const int64_t* a, const int64_t* p, const int64_t* n, int64_t T,
+                                   float margin, int kind, int64_t* a_out, int64_t* p_out, int64_t* n_out, int64_t* count,
+                                   void* ws, size_t ws_bytes, hpcs_stream_t stream) {
+    if (!xn || !a || !p || !n || !a_out || !p_out || !n_out || !count || !ws) return HPCS_ERR_NULL;
+    if (E <= 0 || T < 0 || kind < 0 || kind > 3) return HPCS_ERR_SHAPE;
+    if (ws_bytes < hpcs_triplet_filter_workspace(T)) return HPCS_ERR_WORKSPACE;
+    if (T == 0) {
+        if (hipMemsetAsync(count, 0, sizeof(int64_t), ST) != hipSuccess) return HPCS_ERR_HIP;
+        return HPCS_OK;
+    }
+    const int64_t nb = (T + CHUNK - 1) / CHUNK;
+    uint8_t* flags = (uint8_t*)ws;
+    char* q = (char*)ws + ((T + 15) / 16) * 16;
+    int32_t* block_cnt = (int32_t*)q;
+    q += ((nb * sizeof(int32_t) + 15) / 16) * 16;
+    int64_t* block_off = (int64_t*)q;
+    hipLaunchKernelGGL(filter_flag_kernel, dim3((unsigned)nb), dim3(TPB), 0, ST, xn, E, a, p, n, T, margin, kind, flags,
+                       block_cnt);
+    HPCS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(filter_scan_kernel, dim3(1), dim3(64), 0, ST, block_cnt, (int)nb, block_off, count);
+    HPCS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(filter_scatter_kernel, dim3((unsigned)nb), dim3(TPB), 0, ST, flags, block_off, a, p, n, T, a_out, p_out,
+                       n_out);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
+extern "C" int hpcs_hyphc_fwd(const float* xn, int E, const int64_t* a, const int64_t* p, const int64_t* n,
+                              const int64_t* count, int64_t T_cap, const float* scale, float temperature, double* loss_sum,
+                              hpcs_stream_t stream) {
+    if (!xn || !a || !p || !n || !count || !scale || !loss_sum) return HPCS_ERR_NULL;
+    if (E <= 0 || T_cap < 0 || !(temperature > 0.f)) return HPCS_ERR_SHAPE;
+    if (hipMemsetAsync(loss_sum, 0, sizeof(double), ST) != hipSuccess) return HPCS_ERR_HIP;
+    if (T_cap == 0) return HPCS_OK;
+    hipLaunchKernelGGL(hyphc_fwd_kernel, dim3(trip_grid(T_cap)), dim3(TPB), 0, ST, xn, E, a, p, n, count, T_cap, scale,
+                       temperature, loss_sum);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
+extern "C" int hpcs_hyphc_bwd(const float* xn, int E, const int64_t* a, const int64_t* p, const int64_t* n,
+                              const int64_t* count, int64_t T_cap, const float* scale, float temperature,
+                              const float* gloss, float* gxn, double* gscale, hpcs_stream_t stream) {
+    if (!xn || !a || !p || !n || !count || !scale || !gloss || !gxn || !gscale) return HPCS_ERR_NULL;
+    if (E <= 0 || T_cap < 0 || !(temperature > 0.f)) return HPCS_ERR_SHAPE;
+    if (hipMemsetAsync(gscale, 0, sizeof(double), ST) != hipSuccess) return HPCS_ERR_HIP;
+    if (T_cap == 0) return HPCS_OK;
+    hipLaunchKernelGGL(hyphc_bwd_kernel, dim3(trip_grid(T_cap)), dim3(TPB), 0, ST, xn, E, a, p, n, count, T_cap, scale,
+                       temperature, gloss, gxn, gscale);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
+extern "C" int hpcs_cosface_fwd(const float* xn, const float* wn, const int64_t* labels, int M, int E, int C, float margin,
+                                float scale, float* logits, float* loss_rows, hpcs_stream_t stream) {
+    if (!xn || !wn || !labels || !logits || !loss_rows) return HPCS_ERR_NULL;
+    if (M < 0 || E <= 0 || C <= 0 || (size_t)C * E * 4 > 64 * 1024) return HPCS_ERR_SHAPE;
+    if (M == 0) return HPCS_OK;
+    hipLaunchKernelGGL(cosface_fwd_kernel, dim3(hpcs_cdiv(M, 64)), dim3(64), (size_t)C * E * 4, ST, xn, wn, labels, M, E, C,
+                       margin, scale, logits, loss_rows);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
+extern "C" int hpcs_cosface_bwd(const float* xn, const float* wn, const int64_t* labels, const float* logits,
+                                const float* loss_rows, int M, int E, int C, float scale, const float* gloss, float* gxn,
+                                float* gwn, hpcs_stream_t stream) {
+    if (!xn || !wn || !labels || !logits || !loss_rows || !gloss || !gxn || !gwn) return HPCS_ERR_NULL;
+    if (M < 0 || E <= 0 || C <= 0 || (size_t)C * E * 4 > 64 * 1024) return HPCS_ERR_SHAPE;
+    if (M == 0) {
+        if (hipMemsetAsync(gwn, 0, sizeof(float) * C * E, ST) != hipSuccess) return HPCS_ERR_HIP;
+        return HPCS_OK;
+    }
+    hipLaunchKernelGGL(cosface_bwd_x_kernel, dim3(hpcs_cdiv(M, 64)), dim3(64), (size_t)C * E * 4, ST, wn, labels, logits, M, E,
+                       C, scale, gloss, gxn);
+    HPCS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(cosface_bwd_w_kernel, dim3(C), dim3(TPB), 0, ST, xn, labels, logits, loss_rows, M, E, C, scale,
+                       gloss, gwn);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
+extern "C" int hpcs_triplet_margin_fwd(const float* xn, int E, const int64_t* a, const int64_t* p, const int64_t* n,
+                                       const int64_t* count, int64_t T_cap, float margin, double* sum_and_nnz,
+                                       hpcs_stream_t stream) {
+    if (!xn || !a || !p || !n || !count || !sum_and_nnz) return HPCS_ERR_NULL;
+    if (E <= 0 || T_cap < 0) return HPCS_ERR_SHAPE;
+    if (hipMemsetAsync(sum_and_nnz, 0, 2 * sizeof(double), ST) != hipSuccess) return HPCS_ERR_HIP;
+    if (T_cap == 0) return HPCS_OK;
+    hipLaunchKernelGGL(triplet_margin_fwd_kernel, dim3(trip_grid(T_cap)), dim3(TPB), 0, ST, xn, E, a, p, n, count, T_cap,
+                       margin, sum_and_nnz);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
+extern "C" int hpcs_triplet_margin_bwd(const float* xn, int E, const int64_t* a, const int64_t* p, const int64_t* n,
+                                       const int64_t* count, int64_t T_cap, float margin, const double* sum_and_nnz,
+                                       const float* gloss, float* gxn, hpcs_stream_t stream) {
+    if (!xn || !a || !p || !n || !count || !sum_and_nnz || !gloss || !gxn) return HPCS_ERR_NULL;
+    if (E <= 0 || T_cap < 0) return HPCS_ERR_SHAPE;
+    if (T_cap == 0) return HPCS_OK;
+    hipLaunchKernelGGL(triplet_margin_bwd_kernel, dim3(trip_grid(T_cap)), dim3(TPB), 0, ST, xn, E, a, p, n, count, T_cap,
+                       margin, sum_and_nnz, gloss, gxn);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}

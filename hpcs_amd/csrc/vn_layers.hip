@@ -1,0 +1,893 @@
+// a2-a6: the element-wise / reduction side of the Vector-Neuron layers (everything around the channel GEMMs).
+//
+// Replaces get_graph_feature (vn_dgcnn_util.py:13-41), VNBatchNorm (vn_layers.py:112-132), the VN-LeakyReLU
+// of VNLinearLeakyReLU (vn_layers.py:66-77), mean_pool / VNMaxPool (vn_layers.py:135-153), the frame einsum of
+// VNStdFeature (vn_layers.py:197) and the mean/max/concat glue of VN_DGCNN_partseg.forward
+// (vn_dgcnn_partseg.py:79-95) plus the Conv1d heads' BatchNorm1d+LeakyReLU+Dropout (:40-57).
+//
+// All kernels are HBM-bound streaming passes over [B,C,3,L] tensors with L contiguous: threads run along L
+// (coalesced 4-byte lanes, three xyz planes L apart), one grid.y slice per channel, per-channel BatchNorm
+// reductions accumulate in double through one atomic per workgroup.
+#include "common.h"
+
+namespace {
+
+constexpr float VN_EPS = 1e-6f;
+constexpr int TPB = 256;
+constexpr int ITEMS = 8;   // elements of the flattened (b,l) axis per thread in reduction kernels
+
+// ------------------------------------------------------------------------------------------------ a2
+__global__ void edge_gather_fwd_kernel(const float* __restrict__ x, const int64_t* __restrict__ idx, int C, int N, int k,
+                                       float* __restrict__ out) {
+    const int64_t L = (int64_t)N * k;
+    const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= L) return;
+    const int c = blockIdx.y, b = blockIdx.z;
+    const int n = (int)(l / k);
+    const int64_t j = idx[(int64_t)b * L + l];
+    const float* xb = x + ((int64_t)b * C + c) * 3 * N;
+    float* o_diff = out + (((int64_t)b * 2 * C + c) * 3) * L + l;
+    float* o_ctr = out + (((int64_t)b * 2 * C + C + c) * 3) * L + l;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float ctr = xb[(int64_t)a * N + n];
+        const float nb = xb[(int64_t)a * N + j];
+        o_diff[(int64_t)a * L] = nb - ctr;
+        o_ctr[(int64_t)a * L] = ctr;
+    }
+}
+
+// centre part: gx[b,c,a,n] = sum_j (g_ctr - g_diff)
+__global__ void edge_gather_bwd_center_kernel(const float* __restrict__ gout, int C, int N, int k, float* __restrict__ gx) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int c = blockIdx.y, b = blockIdx.z;
+    const int64_t L = (int64_t)N * k;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float* gd = gout + (((int64_t)b * 2 * C + c) * 3 + a) * L + (int64_t)n * k;
+        const float* gc = gout + (((int64_t)b * 2 * C + C + c) * 3 + a) * L + (int64_t)n * k;
+        float s = 0.f;
+        for (int j = 0; j < k; ++j) s += gc[j] - gd[j];
+        gx[(((int64_t)b * C + c) * 3 + a) * N + n] = s;
+    }
+}
+
+__global__ void edge_gather_bwd_scatter_kernel(const float* __restrict__ gout, const int64_t* __restrict__ idx, int C, int N,
+                                               int k, float* __restrict__ gx) {
+    const int64_t L = (int64_t)N * k;
+    const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= L) return;
+    const int c = blockIdx.y, b = blockIdx.z;
+    const int64_t j = idx[(int64_t)b * L + l];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float g = gout[(((int64_t)b * 2 * C + c) * 3 + a) * L + l];
+        atomicAdd(gx + (((int64_t)b * C + c) * 3 + a) * N + j, g);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ a3
+struct VnPoint {   // recomputed forward state of one (b,c,l) vector
+    float p[3], d[3], n, xhat, nb, q[3], dot, dsq;
+    bool keep;
+};
+
+__device__ __forceinline__ void vn_forward_point(VnPoint& s, float mean, float rstd, float gamma, float beta, int flags) {
+    const float pn = sqrtf(s.p[0] * s.p[0] + s.p[1] * s.p[1] + s.p[2] * s.p[2]);
+    s.n = pn + VN_EPS;
+    if (flags & HPCS_VN_BN) {
+        s.xhat = (s.n - mean) * rstd;
+        s.nb = s.xhat * gamma + beta;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) s.q[a] = s.p[a] / s.n * s.nb;
+    } else {
+        s.xhat = 0.f;
+        s.nb = 1.f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) s.q[a] = s.p[a];
+    }
+    s.dot = s.q[0] * s.d[0] + s.q[1] * s.d[1] + s.q[2] * s.d[2];
+    s.dsq = s.d[0] * s.d[0] + s.d[1] * s.d[1] + s.d[2] * s.d[2];
+    s.keep = !(flags & HPCS_VN_LRELU) || (s.dot >= 0.f);
+}
+
+__device__ __forceinline__ void vn_output_point(const VnPoint& s, float slope, int flags, float (&o)[3]) {
+    if (!(flags & HPCS_VN_LRELU)) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) o[a] = s.q[a];
+        return;
+    }
+    const float t = s.dot / (s.dsq + VN_EPS);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float inner = s.keep ? s.q[a] : (s.q[a] - t * s.d[a]);
+        o[a] = slope * s.q[a] + (1.f - slope) * inner;
+    }
+}
+
+// gradient wrt q and d of one vector given g = dL/dout
+__device__ __forceinline__ void vn_lrelu_bwd_point(const VnPoint& s, const float (&g)[3], float slope, int flags,
+                                                   float (&gq)[3], float (&gd)[3]) {
+    if (s.keep) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            gq[a] = g[a];
+            gd[a] = 0.f;
+        }
+        return;
+    }
+    const float a1 = 1.f - slope;
+    const float den = s.dsq + VN_EPS;
+    const float t = s.dot / den;
+    const float gdot = g[0] * s.d[0] + g[1] * s.d[1] + g[2] * s.d[2];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        gq[a] = g[a] - a1 * (gdot / den) * s.d[a];
+        gd[a] = -a1 * (t * g[a] + gdot * (s.q[a] - 2.f * t * s.d[a]) / den);
+    }
+}
+
+__device__ __forceinline__ void load3(const float* __restrict__ base, int64_t L, float (&v)[3]) {
+    v[0] = base[0];
+    v[1] = base[L];
+    v[2] = base[2 * L];
+}
+
+__global__ void vn_norm_stats_kernel(const float* __restrict__ PD, int B, int Ctot, int64_t L, int Cout,
+                                     double* __restrict__ sums) {
+    __shared__ double red[16];
+    const int c = blockIdx.y;
+    const int64_t total = (int64_t)B * L;
+    const int64_t e0 = (int64_t)blockIdx.x * (TPB * ITEMS) + threadIdx.x;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const int64_t e = e0 + (int64_t)it * TPB;
+        if (e < total) {
+            const int64_t b = e / L, l = e % L;
+            float p[3];
+            load3(PD + ((b * Ctot + c) * 3) * L + l, L, p);
+            const float n = sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]) + VN_EPS;
+            s1 += n;
+            s2 += n * n;
+        }
+    }
+    const double r1 = hpcs_block_sum<double>((double)s1, red);
+    const double r2 = hpcs_block_sum<double>((double)s2, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(sums + c, r1);
+        atomicAdd(sums + Cout + c, r2);
+    }
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, int C, double count, float eps, float momentum,
+                                   float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ mean,
+                                   float* __restrict__ rstd, int training) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    if (training) {
+        const double m = sums[c] / count;
+        double var = sums[C + c] / count - m * m;
+        if (var < 0.0) var = 0.0;
+        mean[c] = (float)m;
+        rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (rmean) rmean[c] = (float)((1.0 - momentum) * rmean[c] + momentum * m);
+        if (rvar) {
+            const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+            rvar[c] = (float)((1.0 - momentum) * rvar[c] + momentum * unb);
+        }
+    } else {
+        mean[c] = rmean[c];
+        rstd[c] = 1.0f / sqrtf(rvar[c] + eps);
+    }
+}
+
+__global__ void vn_apply_fwd_kernel(const float* __restrict__ PD, const float* __restrict__ mean,
+                                    const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                    const float* __restrict__ beta, int B, int Cout, int Cd, int64_t L, float slope,
+                                    int flags, float* __restrict__ out) {
+    const int c = blockIdx.y;
+    const int Ctot = Cout + Cd;
+    const int cd = Cd == 1 ? Cout : Cout + c;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (int64_t)B * L) return;
+    const int64_t b = e / L, l = e % L;
+    VnPoint s;
+    load3(PD + ((b * Ctot + c) * 3) * L + l, L, s.p);
+    if (flags & HPCS_VN_LRELU) load3(PD + ((b * Ctot + cd) * 3) * L + l, L, s.d);
+    else s.d[0] = s.d[1] = s.d[2] = 0.f;
+    const bool bn = flags & HPCS_VN_BN;
+    vn_forward_point(s, bn ? mean[c] : 0.f, bn ? rstd[c] : 1.f, bn ? gamma[c] : 1.f, bn ? beta[c] : 0.f, flags);
+    float o[3];
+    vn_output_point(s, slope, flags, o);
+    float* op = out + ((b * Cout + c) * 3) * L + l;
+    op[0] = o[0];
+    op[L] = o[1];
+    op[2 * L] = o[2];
+}
+
+// fused mean_pool over groups of pool_k consecutive l: one thread per (b, n)
+__global__ void vn_apply_pool_fwd_kernel(const float* __restrict__ PD, const float* __restrict__ mean,
+                                         const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                         const float* __restrict__ beta, int B, int Cout, int Cd, int64_t L, int pool_k,
+                                         float slope, int flags, float* __restrict__ out) {
+    const int c = blockIdx.y;
+    const int Ctot = Cout + Cd;
+    const int cd = Cd == 1 ? Cout : Cout + c;
+    const int64_t Np = L / pool_k;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (int64_t)B * Np) return;
+    const int64_t b = e / Np, n = e % Np;
+    const bool bn = flags & HPCS_VN_BN;
+    const float mu = bn ? mean[c] : 0.f, rs = bn ? rstd[c] : 1.f, ga = bn ? gamma[c] : 1.f, be = bn ? beta[c] : 0.f;
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int j = 0; j < pool_k; ++j) {
+        const int64_t l = n * pool_k + j;
+        VnPoint s;
+        load3(PD + ((b * Ctot + c) * 3) * L + l, L, s.p);
+        if (flags & HPCS_VN_LRELU) load3(PD + ((b * Ctot + cd) * 3) * L + l, L, s.d);
+        else s.d[0] = s.d[1] = s.d[2] = 0.f;
+        vn_forward_point(s, mu, rs, ga, be, flags);
+        float o[3];
+        vn_output_point(s, slope, flags, o);
+        acc[0] += o[0];
+        acc[1] += o[1];
+        acc[2] += o[2];
+    }
+    float* op = out + ((b * Cout + c) * 3) * Np + n;
+    const float inv = 1.f / (float)pool_k;
+    op[0] = acc[0] * inv;
+    op[Np] = acc[1] * inv;
+    op[2 * Np] = acc[2] * inv;
+}
+
+__device__ __forceinline__ void load_gout(const float* __restrict__ gout, int64_t b, int Cout, int c, int64_t L, int64_t l,
+                                          int pool_k, float (&g)[3]) {
+    if (pool_k > 0) {
+        const int64_t Np = L / pool_k;
+        const float inv = 1.f / (float)pool_k;
+        const float* gp = gout + ((b * Cout + c) * 3) * Np + l / pool_k;
+        g[0] = gp[0] * inv;
+        g[1] = gp[Np] * inv;
+        g[2] = gp[2 * Np] * inv;
+    } else {
+        load3(gout + ((b * Cout + c) * 3) * L + l, L, g);
+    }
+}
+
+__global__ void vn_bwd_reduce_kernel(const float* __restrict__ PD, const float* __restrict__ gout,
+                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                     const float* __restrict__ gamma, const float* __restrict__ beta, int B, int Cout,
+                                     int Cd, int64_t L, int pool_k, float slope, int flags, double* __restrict__ red_out) {
+    __shared__ double red[16];
+    const int c = blockIdx.y;
+    const int Ctot = Cout + Cd;
+    const int cd = Cd == 1 ? Cout : Cout + c;
+    const int64_t total = (int64_t)B * L;
+    const int64_t e0 = (int64_t)blockIdx.x * (TPB * ITEMS) + threadIdx.x;
+    const float mu = mean[c], rs = rstd[c], ga = gamma[c], be = beta[c];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll 2
+    for (int it = 0; it < ITEMS; ++it) {
+        const int64_t e = e0 + (int64_t)it * TPB;
+        if (e < total) {
+            const int64_t b = e / L, l = e % L;
+            VnPoint s;
+            load3(PD + ((b * Ctot + c) * 3) * L + l, L, s.p);
+            if (flags & HPCS_VN_LRELU) load3(PD + ((b * Ctot + cd) * 3) * L + l, L, s.d);
+            else s.d[0] = s.d[1] = s.d[2] = 0.f;
+            vn_forward_point(s, mu, rs, ga, be, flags);
+            float g[3], gq[3], gd[3];
+            load_gout(gout, b, Cout, c, L, l, pool_k, g);
+            vn_lrelu_bwd_point(s, g, slope, flags, gq, gd);
+            const float gnb = (gq[0] * s.p[0] + gq[1] * s.p[1] + gq[2] * s.p[2]) / s.n;
+            s1 += gnb;
+            s2 += gnb * s.xhat;
+        }
+    }
+    const double r1 = hpcs_block_sum<double>((double)s1, red);
+    const double r2 = hpcs_block_sum<double>((double)s2, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(red_out + c, r1);
+        atomicAdd(red_out + Cout + c, r2);
+    }
+}
+
+template <bool SHARED>
+__global__ void vn_bwd_apply_kernel(const float* __restrict__ PD, const float* __restrict__ gout,
+                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    const double* __restrict__ red, int training, int B, int Cout, int Cd, int64_t L,
+                                    int pool_k, float slope, int flags, float* __restrict__ GPD) {
+    const int Ctot = Cout + Cd;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (int64_t)B * L) return;
+    const int64_t b = e / L, l = e % L;
+    const double count = (double)B * (double)L;
+    const int c_begin = SHARED ? 0 : blockIdx.y;
+    const int c_end = SHARED ? Cout : blockIdx.y + 1;
+    const bool bn = flags & HPCS_VN_BN;
+    float gdsum[3] = {0.f, 0.f, 0.f};
+    float dsh[3] = {0.f, 0.f, 0.f};
+    if (SHARED && (flags & HPCS_VN_LRELU)) load3(PD + ((b * Ctot + Cout) * 3) * L + l, L, dsh);
+    for (int c = c_begin; c < c_end; ++c) {
+        VnPoint s;
+        load3(PD + ((b * Ctot + c) * 3) * L + l, L, s.p);
+        if (SHARED) {
+            s.d[0] = dsh[0]; s.d[1] = dsh[1]; s.d[2] = dsh[2];
+        } else if (flags & HPCS_VN_LRELU) {
+            load3(PD + ((b * Ctot + Cout + c) * 3) * L + l, L, s.d);
+        } else {
+            s.d[0] = s.d[1] = s.d[2] = 0.f;
+        }
+        const float mu = bn ? mean[c] : 0.f, rs = bn ? rstd[c] : 1.f, ga = bn ? gamma[c] : 1.f, be = bn ? beta[c] : 0.f;
+        vn_forward_point(s, mu, rs, ga, be, flags);
+        float g[3], gq[3], gd[3];
+        load_gout(gout, b, Cout, c, L, l, pool_k, g);
+        vn_lrelu_bwd_point(s, g, slope, flags, gq, gd);
+        float gp[3];
+        if (bn) {
+            const float gqp = gq[0] * s.p[0] + gq[1] * s.p[1] + gq[2] * s.p[2];
+            const float gnb = gqp / s.n;
+            float gn = -gqp * s.nb / (s.n * s.n);
+            const float gxh = gnb * ga;
+            if (training) {
+                const float m1 = (float)(red[c] / count) * ga;
+                const float m2 = (float)(red[Cout + c] / count) * ga;
+                gn += rs * (gxh - m1 - s.xhat * m2);
+            } else {
+                gn += rs * gxh;
+            }
+            const float pn = s.n - VN_EPS;
+            const float sc = s.nb / s.n;
+            const float dirw = pn > 0.f ? gn / pn : 0.f;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) gp[a] = gq[a] * sc + dirw * s.p[a];
+        } else {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) gp[a] = gq[a];
+        }
+        float* o = GPD + ((b * Ctot + c) * 3) * L + l;
+        o[0] = gp[0];
+        o[L] = gp[1];
+        o[2 * L] = gp[2];
+        if (SHARED) {
+            gdsum[0] += gd[0]; gdsum[1] += gd[1]; gdsum[2] += gd[2];
+        } else if (Cd > 0) {
+            float* od = GPD + ((b * Ctot + Cout + c) * 3) * L + l;
+            od[0] = gd[0];
+            od[L] = gd[1];
+            od[2 * L] = gd[2];
+        }
+    }
+    if (SHARED) {
+        float* od = GPD + ((b * Ctot + Cout) * 3) * L + l;
+        od[0] = gdsum[0];
+        od[L] = gdsum[1];
+        od[2 * L] = gdsum[2];
+    }
+}
+
+// ------------------------------------------------------------------------------ Conv1d heads: BN1d + act + mask
+__global__ void bn_stats_kernel(const float* __restrict__ Y, int B, int C, int64_t L, double* __restrict__ sums) {
+    __shared__ double red[16];
+    const int c = blockIdx.y;
+    const int64_t total = (int64_t)B * L;
+    const int64_t e0 = (int64_t)blockIdx.x * (TPB * ITEMS) + threadIdx.x;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const int64_t e = e0 + (int64_t)it * TPB;
+        if (e < total) {
+            const float y = Y[((e / L) * C + c) * L + e % L];
+            s1 += y;
+            s2 += y * y;
+        }
+    }
+    const double r1 = hpcs_block_sum<double>((double)s1, red);
+    const double r2 = hpcs_block_sum<double>((double)s2, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(sums + c, r1);
+        atomicAdd(sums + C + c, r2);
+    }
+}
+
+__global__ void bn_act_fwd_kernel(const float* __restrict__ Y, const float* __restrict__ mean,
+                                  const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                  const float* __restrict__ beta, const float* __restrict__ mask, int B, int C, int64_t L,
+                                  float slope, float* __restrict__ out) {
+    const int c = blockIdx.y;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (int64_t)B * L) return;
+    const int64_t off = ((e / L) * C + c) * L + e % L;
+    const float z = (Y[off] - mean[c]) * rstd[c] * gamma[c] + beta[c];
+    float o = z > 0.f ? z : z * slope;
+    if (mask) o *= mask[off];
+    out[off] = o;
+}
+
+__global__ void bn_act_bwd_reduce_kernel(const float* __restrict__ Y, const float* __restrict__ gout,
+                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                         const float* __restrict__ mask, int B, int C, int64_t L, float slope,
+                                         double* __restrict__ red_out) {
+    __shared__ double red[16];
+    const int c = blockIdx.y;
+    const int64_t total = (int64_t)B * L;
+    const int64_t e0 = (int64_t)blockIdx.x * (TPB * ITEMS) + threadIdx.x;
+    const float mu = mean[c], rs = rstd[c], ga = gamma[c], be = beta[c];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const int64_t e = e0 + (int64_t)it * TPB;
+        if (e < total) {
+            const int64_t off = ((e / L) * C + c) * L + e % L;
+            const float xh = (Y[off] - mu) * rs;
+            const float z = xh * ga + be;
+            float g = gout[off];
+            if (mask) g *= mask[off];
+            g *= z > 0.f ? 1.f : slope;
+            s1 += g;
+            s2 += g * xh;
+        }
+    }
+    const double r1 = hpcs_block_sum<double>((double)s1, red);
+    const double r2 = hpcs_block_sum<double>((double)s2, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(red_out + c, r1);
+        atomicAdd(red_out + C + c, r2);
+    }
+}
+
+__global__ void bn_act_bwd_apply_kernel(const float* __restrict__ Y, const float* __restrict__ gout,
+                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                        const float* __restrict__ mask, const double* __restrict__ red, int training,
+                                        int B, int C, int64_t L, float slope, float* __restrict__ gY) {
+    const int c = blockIdx.y;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (int64_t)B * L) return;
+    const double count = (double)B * (double)L;
+    const int64_t off = ((e / L) * C + c) * L + e % L;
+    const float rs = rstd[c], ga = gamma[c];
+    const float xh = (Y[off] - mean[c]) * rs;
+    const float z = xh * ga + beta[c];
+    float g = gout[off];
+    if (mask) g *= mask[off];
+    g *= z > 0.f ? 1.f : slope;
+    float r;
+    if (training) {
+        const float m1 = (float)(red[c] / count), m2 = (float)(red[C + c] / count);
+        r = rs * ga * (g - m1 - xh * m2);
+    } else {
+        r = rs * ga * g;
+    }
+    gY[off] = r;
+}
+
+// ------------------------------------------------------------------------------ glue
+// one workgroup per (b,c,a) row
+__global__ void concat_mean_fwd_kernel(const float* __restrict__ x, int C, int N, float* __restrict__ out) {
+    __shared__ float red[16];
+    __shared__ float mval;
+    const int64_t row = blockIdx.x;            // over B*C*3
+    const int64_t b = row / (3 * C), r = row % (3 * C);
+    const float* xr = x + row * N;
+    float* o1 = out + (b * 2 * C * 3 + r) * N;
+    float* o2 = out + (b * 2 * C * 3 + 3 * C + r) * N;
+    float s = 0.f;
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        const float v = xr[n];
+        o1[n] = v;
+        s += v;
+    }
+    const float t = hpcs_block_sum<float>(s, red);
+    if (threadIdx.x == 0) mval = t / (float)N;
+    __syncthreads();
+    const float m = mval;
+    for (int n = threadIdx.x; n < N; n += blockDim.x) o2[n] = m;
+}
+
+__global__ void concat_mean_bwd_kernel(const float* __restrict__ gout, int C, int N, float* __restrict__ gx) {
+    __shared__ float red[16];
+    __shared__ float mval;
+    const int64_t row = blockIdx.x;
+    const int64_t b = row / (3 * C), r = row % (3 * C);
+    const float* g1 = gout + (b * 2 * C * 3 + r) * N;
+    const float* g2 = gout + (b * 2 * C * 3 + 3 * C + r) * N;
+    float s = 0.f;
+    for (int n = threadIdx.x; n < N; n += blockDim.x) s += g2[n];
+    const float t = hpcs_block_sum<float>(s, red);
+    if (threadIdx.x == 0) mval = t / (float)N;
+    __syncthreads();
+    const float m = mval;
+    for (int n = threadIdx.x; n < N; n += blockDim.x) gx[row * N + n] = g1[n] + m;
+}
+
+__global__ void frame_project_fwd_kernel(const float* __restrict__ x, const float* __restrict__ z, int C, int N,
+                                         float* __restrict__ out) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= N) return;
+    const int i = blockIdx.y, b = blockIdx.z;
+    const float* xp = x + ((int64_t)(b * C + i) * 3) * N + m;
+    const float* zp = z + ((int64_t)b * 9) * N + m;
+    const float x0 = xp[0], x1 = xp[N], x2 = xp[2 * (int64_t)N];
+    float* op = out + ((int64_t)(b * C + i) * 3) * N + m;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        op[(int64_t)k * N] = x0 * zp[(int64_t)(0 * 3 + k) * N] + x1 * zp[(int64_t)(1 * 3 + k) * N] + x2 * zp[(int64_t)(2 * 3 + k) * N];
+}
+
+// one thread per (b, m): loops channels, writes gx, accumulates gz
+__global__ void frame_project_bwd_kernel(const float* __restrict__ x, const float* __restrict__ z,
+                                         const float* __restrict__ gout, int C, int N, float* __restrict__ gx,
+                                         float* __restrict__ gz) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= N) return;
+    const int b = blockIdx.y;
+    float zz[9], gzz[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        zz[t] = z[((int64_t)b * 9 + t) * N + m];
+        gzz[t] = 0.f;
+    }
+    for (int i = 0; i < C; ++i) {
+        const int64_t base = ((int64_t)(b * C + i) * 3) * N + m;
+        float xv[3], gv[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            xv[a] = x[base + (int64_t)a * N];
+            gv[a] = gout[base + (int64_t)a * N];
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            gx[base + (int64_t)j * N] = gv[0] * zz[j * 3 + 0] + gv[1] * zz[j * 3 + 1] + gv[2] * zz[j * 3 + 2];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) gzz[j * 3 + k] += xv[j] * gv[k];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) gz[((int64_t)b * 9 + t) * N + m] = gzz[t];
+}
+
+__global__ void rowmax_fwd_kernel(const float* __restrict__ x, int64_t L, float* __restrict__ out, int32_t* __restrict__ arg) {
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    const int64_t row = blockIdx.x;
+    const float* xr = x + row * L;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int64_t l = threadIdx.x; l < L; l += blockDim.x) {
+        const float v = xr[l];
+        if (v > bv || (v == bv && (int)l < bi)) { bv = v; bi = (int)l; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if (lane == 0) { sv[w] = bv; si[w] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < nw; ++i)
+            if (sv[i] > bv || (sv[i] == bv && si[i] < bi)) { bv = sv[i]; bi = si[i]; }
+        out[row] = bv;
+        if (arg) arg[row] = bi;
+    }
+}
+
+__global__ void rowmax_bwd_kernel(const float* __restrict__ gout, const int32_t* __restrict__ arg, int64_t rows, int64_t L,
+                                  float* __restrict__ gx) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= rows * L) return;
+    const int64_t row = e / L, l = e % L;
+    gx[e] = (int)l == arg[row] ? gout[row] : 0.f;
+}
+
+__global__ void rowsum_kernel(const float* __restrict__ x, int64_t L, float scale, float* __restrict__ out) {
+    __shared__ float red[16];
+    const int64_t row = blockIdx.x;
+    const float* xr = x + row * L;
+    float s = 0.f;
+    for (int64_t l = threadIdx.x; l < L; l += blockDim.x) s += xr[l];
+    const float t = hpcs_block_sum<float>(s, red);
+    if (threadIdx.x == 0) out[row] = t * scale;
+}
+
+__global__ void vn_maxpool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ d, int C, int N, int k,
+                                      float* __restrict__ out, int32_t* __restrict__ arg) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int c = blockIdx.y, b = blockIdx.z;
+    const int64_t L = (int64_t)N * k;
+    const int64_t base = ((int64_t)(b * C + c) * 3) * L + (int64_t)n * k;
+    float bv = -INFINITY;
+    int bj = 0;
+    for (int j = 0; j < k; ++j) {
+        const float dot = x[base + j] * d[base + j] + x[base + L + j] * d[base + L + j] + x[base + 2 * L + j] * d[base + 2 * L + j];
+        if (dot > bv) { bv = dot; bj = j; }
+    }
+    const int64_t ob = ((int64_t)(b * C + c) * 3) * N + n;
+    out[ob] = x[base + bj];
+    out[ob + N] = x[base + L + bj];
+    out[ob + 2 * (int64_t)N] = x[base + 2 * L + bj];
+    arg[(int64_t)(b * C + c) * N + n] = bj;
+}
+
+__global__ void vn_maxpool_bwd_kernel(const float* __restrict__ gout, const int32_t* __restrict__ arg, int C, int N, int k,
+                                      float* __restrict__ gx) {
+    const int64_t L = (int64_t)N * k;
+    const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= L) return;
+    const int c = blockIdx.y, b = blockIdx.z;
+    const int n = (int)(l / k), j = (int)(l % k);
+    const bool hit = arg[(int64_t)(b * C + c) * N + n] == j;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+        gx[((int64_t)(b * C + c) * 3 + a) * L + l] = hit ? gout[((int64_t)(b * C + c) * 3 + a) * N + n] : 0.f;
+}
+
+__global__ void scale_inplace_kernel(float* __restrict__ x, int64_t n, float s) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] *= s;
+}
+
+inline bool bad_dims(int B, int C, int64_t L) { return B < 0 || C <= 0 || L <= 0; }
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int hpcs_version(void) { return 100; }
+
+extern "C" int hpcs_edge_gather_fwd(const float* x, const int64_t* idx, int B, int C, int N, int k, float* out,
+                                    hpcs_stream_t stream) {
+    if (!x || !idx || !out) return HPCS_ERR_NULL;
+    if (B < 0 || C <= 0 || N <= 0 || k <= 0 || C > 65535 || B > 65535) return HPCS_ERR_SHAPE;
+    if (B == 0) return HPCS_OK;
+    const int64_t L = (int64_t)N * k;
+    hipLaunchKernelGGL(edge_gather_fwd_kernel, dim3(hpcs_cdiv(L, TPB), C, B), dim3(TPB), 0, ST, x, idx, C, N, k, out);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
+extern "C" int hpcs_edge_gather_bwd(const float* gout, const int64_t* idx, int B, int C, int N, int k, float* gx,
+                                    hpcs_stream_t stream) {
+    if (!gout || !idx || !gx) return HPCS_ERR_NULL;
+    if (B < 0 || C <= 0 || N <= 0 || k <= 0 || C > 65535 || B > 65535) return HPCS_ERR_SHAPE;
+    if (B == 0) return HPCS_OK;
+    const int64_t L = (int64_t)N * k;
+    hipLaunchKernelGGL(edge_gather_bwd_center_kernel, dim3(hpcs_cdiv(N, TPB), C, B), dim3(TPB), 0, ST, gout, C, N, k, gx);
+    HPCS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(edge_gather_bwd_scatter_kernel, dim3(hpcs_cdiv(L, TPB), C, B), dim3(TPB), 0, ST, gout, idx, C, N, k,
+                       gx);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
+extern "C" int hpcs_vn_norm_stats(const float* PD, int B, int Cout, int Ctot, int64_t L, double* sums, hpcs_stream_t stream) {
+    if (!PD || !sums) return HPCS_ERR_NULL;
+    if (bad_dims(B, Cout, L) || Ctot < Cout || Cout > 65535) return HPCS_ERR_SHAPE;
+    if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * Cout, ST) != hipSuccess) return HPCS_ERR_HIP;
+    if (B == 0) return HPCS_OK;
+    hipLaunchKernelGGL(vn_norm_stats_kernel, dim3(hpcs_cdiv((int64_t)B * L, TPB * ITEMS), Cout), dim3(TPB), 0, ST, PD, B,
+                       Ctot, L, Cout, sums);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
+extern "C" int hpcs_bn_finalize(const double* sums, int C, int64_t count, float eps, float momentum, float* running_mean,
+                                float* running_var, float* mean, float* rstd, int training, hpcs_stream_t stream) {
+    if (!mean || !rstd || (training && !sums) || (!training && (!running_mean || !running_var))) return HPCS_ERR_NULL;
+    if (C <= 0 || (training && count <= 0)) return HPCS_ERR_SHAPE;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(hpcs_cdiv(C, 128)), dim3(128), 0, ST, sums, C, (double)count, eps, momentum,
+                       running_mean, running_var, mean, rstd, training);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
+static int vn_args_ok(const void* PD, const void* mean, const void* rstd, const void* gamma, const void* beta, int B,
+                      int Cout, int Cd, int64_t L, int pool_k, int flags) {
+    if (!PD) return HPCS_ERR_NULL;
+    if ((flags & HPCS_VN_BN) && (!mean || !rstd || !gamma || !beta)) return HPCS_ERR_NULL;
+    if (bad_dims(B, Cout, L) || Cout > 65535) return HPCS_ERR_SHAPE;
+    if ((flags & HPCS_VN_LRELU) ? !(Cd == Cout || Cd == 1) : Cd < 0) return HPCS_ERR_SHAPE;
+    if (pool_k < 0 || (pool_k > 0 && L % pool_k != 0)) return HPCS_ERR_SHAPE;
+    return HPCS_OK;
+}
+
+extern "C" int hpcs_vn_apply_fwd(const float* PD, const float* mean, const float* rstd, const float* gamma,
+                                 const float* beta, int B, int Cout, int Cd, int64_t L, int pool_k, float slope, int flags,
+                                 float* out, hpcs_stream_t stream) {
+    int rc = vn_args_ok(PD, mean, rstd, gamma, beta, B, Cout, Cd, L, pool_k, flags);
+    if (rc) return rc;
+    if (!out) return HPCS_ERR_NULL;
+    if (B == 0) return HPCS_OK;
+    if (pool_k > 0)
+        hipLaunchKernelGGL(vn_apply_pool_fwd_kernel, dim3(hpcs_cdiv((int64_t)B * (L / pool_k), TPB), Cout), dim3(TPB), 0,
+                           ST, PD, mean, rstd, gamma, beta, B, Cout, Cd, L, pool_k, slope, flags, out);
+    else
+        hipLaunchKernelGGL(vn_apply_fwd_kernel, dim3(hpcs_cdiv((int64_t)B * L, TPB), Cout), dim3(TPB), 0, ST, PD, mean,
+                           rstd, gamma, beta, B, Cout, Cd, L, slope, flags, out);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
+extern "C" int hpcs_vn_bwd_reduce(const float* PD, const float* gout, const float* mean, const float* rstd,
+                                  const float* gamma, const float* beta, int B, int Cout, int Cd, int64_t L, int pool_k,
+                                  float slope, int flags, double* red, hpcs_stream_t stream) {
+    int rc = vn_args_ok(PD, mean, rstd, gamma, beta, B, Cout, Cd, L, pool_k, flags);
+    if (rc) return rc;
+    if (!gout || !red) return HPCS_ERR_NULL;
+    if (!(flags & HPCS_VN_BN)) return HPCS_ERR_UNSUPPORTED;
+    if (hipMemsetAsync(red, 0, sizeof(double) * 2 * Cout, ST) != hipSuccess) return HPCS_ERR_HIP;
+    if (B == 0) return HPCS_OK;
+    hipLaunchKernelGGL(vn_bwd_reduce_kernel, dim3(hpcs_cdiv((int64_t)B * L, TPB * ITEMS), Cout), dim3(TPB), 0, ST, PD, gout,
+                       mean, rstd, gamma, beta, B, Cout, Cd, L, pool_k, slope, flags, red);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
+extern "C" int hpcs_vn_bwd_apply(const float* PD, const float* gout, const float* mean, const float* rstd,
+                                 const float* gamma, const float* beta, const double* red, int training, int B, int Cout,
+                                 int Cd, int64_t L, int pool_k, float slope, int flags, float* GPD, hpcs_stream_t stream) {
+    int rc = vn_args_ok(PD, mean, rstd, gamma, beta, B, Cout, Cd, L, pool_k, flags);
+    if (rc) return rc;
+    if (!gout || !GPD) return HPCS_ERR_NULL;
+    if ((flags & HPCS_VN_BN) && training && !red) return HPCS_ERR_NULL;
+    if (B == 0) return HPCS_OK;
+    if (Cd == 1 && (flags & HPCS_VN_LRELU))
+        hipLaunchKernelGGL((vn_bwd_apply_kernel<true>), dim3(hpcs_cdiv((int64_t)B * L, TPB), 1), dim3(TPB), 0, ST, PD, gout,
+                           mean, rstd, gamma, beta, red, training, B, Cout, Cd, L, pool_k, slope, flags, GPD);
+    else
+        hipLaunchKernelGGL((vn_bwd_apply_kernel<false>), dim3(hpcs_cdiv((int64_t)B * L, TPB), Cout), dim3(TPB), 0, ST, PD,
+                           gout, mean, rstd, gamma, beta, red, training, B, Cout, Cd, L, pool_k, slope, flags, GPD);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
+extern "C" int hpcs_bn_stats(const float* Y, int B, int C, int64_t L, double* sums, hpcs_stream_t stream) {
+    if (!Y || !sums) return HPCS_ERR_NULL;
+    if (bad_dims(B, C, L) || C > 65535) return HPCS_ERR_SHAPE;
+    if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, ST) != hipSuccess) return HPCS_ERR_HIP;
+    if (B == 0) return HPCS_OK;
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(hpcs_cdiv((int64_t)B * L, TPB * ITEMS), C), dim3(TPB), 0, ST, Y, B, C, L, sums);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
+extern "C" int hpcs_bn_act_fwd(const float* Y, const float* mean, const float* rstd, const float* gamma,
+                               const float* beta, const float* mask, int B, int C, int64_t L, float slope, float* out,
+                               hpcs_stream_t stream) {
+    if (!Y || !mean || !rstd || !gamma || !beta || !out) return HPCS_ERR_NULL;
+    if (bad_dims(B, C, L) || C > 65535) return HPCS_ERR_SHAPE;
+    if (B == 0) return HPCS_OK;
+    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(hpcs_cdiv((int64_t)B * L, TPB), C), dim3(TPB), 0, ST, Y, mean, rstd, gamma,
+                       beta, mask, B, C, L, slope, out);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
+extern "C" int hpcs_bn_act_bwd_reduce(const float* Y, const float* gout, const float* mean, const float* rstd,
+                                      const float* gamma, const float* beta, const float* mask, int B, int C, int64_t L,
+                                      float slope, double* red, hpcs_stream_t stream) {
+    if (!Y || !gout || !mean || !rstd || !gamma || !beta || !red) return HPCS_ERR_NULL;
+    if (bad_dims(B, C, L) || C > 65535) return HPCS_ERR_SHAPE;
+    if (hipMemsetAsync(red, 0, sizeof(double) * 2 * C, ST) != hipSuccess) return HPCS_ERR_HIP;
+    if (B == 0) return HPCS_OK;
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(hpcs_cdiv((int64_t)B * L, TPB * ITEMS), C), dim3(TPB), 0, ST, Y, gout,
+                       mean, rstd, gamma, beta, mask, B, C, L, slope, red);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
+extern "C" int hpcs_bn_act_bwd_apply(const float* Y, const float* gout, const float* mean, const float* rstd,
+                                     const float* gamma, const float* beta, const float* mask, const double* red,
+                                     int training, int B, int C, int64_t L, float slope, float* gY, hpcs_stream_t stream) {
+    if (!Y || !gout || !mean || !rstd || !gamma || !beta || !gY || (training && !red)) return HPCS_ERR_NULL;
+    if (bad_dims(B, C, L) || C > 65535) return HPCS_ERR_SHAPE;
+    if (B == 0) return HPCS_OK;
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(hpcs_cdiv((int64_t)B * L, TPB), C), dim3(TPB), 0, ST, Y, gout, mean,
+                       rstd, gamma, beta, mask, red, training, B, C, L, slope, gY);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
+extern "C" int hpcs_concat_mean_fwd(const float* x, int B, int C, int N, float* out, hpcs_stream_t stream) {
+    if (!x || !out) return HPCS_ERR_NULL;
+    if (B < 0 || C <= 0 || N <= 0) return HPCS_ERR_SHAPE;
+    if (B == 0) return HPCS_OK;
+    hipLaunchKernelGGL(concat_mean_fwd_kernel, dim3((unsigned)((int64_t)B * C * 3)), dim3(TPB), 0, ST, x, C, N, out);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
+extern "C" int hpcs_concat_mean_bwd(const float* gout, int B, int C, int N, float* gx, hpcs_stream_t stream) {
+    if (!gout || !gx) return HPCS_ERR_NULL;
+    if (B < 0 || C <= 0 || N <= 0) return HPCS_ERR_SHAPE;
+    if (B == 0) return HPCS_OK;
+    hipLaunchKernelGGL(concat_mean_bwd_kernel, dim3((unsigned)((int64_t)B * C * 3)), dim3(TPB), 0, ST, gout, C, N, gx);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
+extern "C" int hpcs_frame_project_fwd(const float* x, const float* z, int B, int C, int N, float* out,
+                                      hpcs_stream_t stream) {
+    if (!x || !z || !out) return HPCS_ERR_NULL;
+    if (B < 0 || C <= 0 || N <= 0 || C > 65535 || B > 65535) return HPCS_ERR_SHAPE;
+    if (B == 0) return HPCS_OK;
+    hipLaunchKernelGGL(frame_project_fwd_kernel, dim3(hpcs_cdiv(N, TPB), C, B), dim3(TPB), 0, ST, x, z, C, N, out);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
+extern "C" int hpcs_frame_project_bwd(const float* x, const float* z, const float* gout, int B, int C, int N, float* gx,
+                                      float* gz, hpcs_stream_t stream) {
+    if (!x || !z || !gout || !gx || !gz) return HPCS_ERR_NULL;
+    if (B < 0 || C <= 0 || N <= 0 || B > 65535) return HPCS_ERR_SHAPE;
+    if (B == 0) return HPCS_OK;
+    hipLaunchKernelGGL(frame_project_bwd_kernel, dim3(hpcs_cdiv(N, 64), B), dim3(64), 0, ST, x, z, gout, C, N, gx, gz);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
+extern "C" int hpcs_rowmax_fwd(const float* x, int64_t rows, int64_t L, float* out, int32_t* arg, hpcs_stream_t stream) {
+    if (!x || !out) return HPCS_ERR_NULL;
+    if (rows < 0 || L <= 0 || L > 0x7fffffff) return HPCS_ERR_SHAPE;
+    if (rows == 0) return HPCS_OK;
+    hipLaunchKernelGGL(rowmax_fwd_kernel, dim3((unsigned)rows), dim3(TPB), 0, ST, x, L, out, arg);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
+extern "C" int hpcs_rowmax_bwd(const float* gout, const int32_t* arg, int64_t rows, int64_t L, float* gx,
+                               hpcs_stream_t stream) {
+    if (!gout || !arg || !gx) return HPCS_ERR_NULL;
+    if (rows < 0 || L <= 0) return HPCS_ERR_SHAPE;
+    if (rows == 0) return HPCS_OK;
+    hipLaunchKernelGGL(rowmax_bwd_kernel, dim3(hpcs_cdiv(rows * L, TPB)), dim3(TPB), 0, ST, gout, arg, rows, L, gx);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
+extern "C" int hpcs_rowsum(const float* x, int64_t rows, int64_t L, float scale, float* out, hpcs_stream_t stream) {
+    if (!x || !out) return HPCS_ERR_NULL;
+    if (rows < 0 || L <= 0) return HPCS_ERR_SHAPE;
+    if (rows == 0) return HPCS_OK;
+    hipLaunchKernelGGL(rowsum_kernel, dim3((unsigned)rows), dim3(L >= 256 ? 256 : 64), 0, ST, x, L, scale, out);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
+extern "C" int hpcs_vn_maxpool_fwd(const float* x, const float* d, int B, int C, int N, int k, float* out, int32_t* arg,
+                                   hpcs_stream_t stream) {
+    if (!x || !d || !out || !arg) return HPCS_ERR_NULL;
+    if (B < 0 || C <= 0 || N <= 0 || k <= 0 || C > 65535 || B > 65535) return HPCS_ERR_SHAPE;
+    if (B == 0) return HPCS_OK;
+    hipLaunchKernelGGL(vn_maxpool_fwd_kernel, dim3(hpcs_cdiv(N, TPB), C, B), dim3(TPB), 0, ST, x, d, C, N, k, out, arg);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
+extern "C" int hpcs_vn_maxpool_bwd(const float* gout, const int32_t* arg, int B, int C, int N, int k, float* gx,
+                                   hpcs_stream_t stream) {
+    if (!gout || !arg || !gx) return HPCS_ERR_NULL;
+    if (B < 0 || C <= 0 || N <= 0 || k <= 0 || C > 65535 || B > 65535) return HPCS_ERR_SHAPE;
+    if (B == 0) return HPCS_OK;
+    hipLaunchKernelGGL(vn_maxpool_bwd_kernel, dim3(hpcs_cdiv((int64_t)N * k, TPB), C, B), dim3(TPB), 0, ST, gout, arg, C, N,
+                       k, gx);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
+extern "C" int hpcs_scale_inplace(float* x, int64_t n, float s, hpcs_stream_t stream) {
+    if (!x) return HPCS_ERR_NULL;
+    if (n < 0) return HPCS_ERR_SHAPE;
+    if (n == 0) return HPCS_OK;
+    hipLaunchKernelGGL(scale_inplace_kernel, dim3(hpcs_cdiv(n, TPB)), dim3(TPB), 0, ST, x, n, s);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}

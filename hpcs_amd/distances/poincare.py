@@ -1,0 +1,72 @@
+"""Mirror of hpcs/distances/poincare.py: Poincare toolbox + HyperbolicDistance (a15)."""
+import torch
+
+from .. import _lib
+from ..utils.math import arctanh, tanh  # noqa: F401
+from ..utils.poincare import (BALL_EPS, MIN_NORM, expmap_1 as expmap, hyp_dist_o, lambda_, mobius_add,  # noqa: F401
+                              project)
+
+
+def _dot(u, v):
+    return (u * v).sum(dim=-1, keepdim=True)
+
+
+def egrad2rgrad(p, dp):
+    """Euclidean -> Riemannian gradient (in place, like the reference): dp / lambda_p^2."""
+    return dp.div_(lambda_(p).square())
+
+
+def inner(x, u, v=None):
+    """Riemannian inner product of tangent vectors at x."""
+    return lambda_(x).square() * _dot(u, u if v is None else v)
+
+
+def gyration(u, v, w):
+    """gyr[u,v]w on the Poincare ball."""
+    uu, vv, uv, uw, vw = _dot(u, u), _dot(v, v), _dot(u, v), _dot(u, w), _dot(v, w)
+    cu = vw * (1 + 2 * uv) - uw * vv
+    cv = -(vw * uu + uw)
+    return w + 2 * (cu * u + cv * v) / (1 + 2 * uv + uu * vv).clamp_min(MIN_NORM)
+
+
+def ptransp(x, y, u):
+    """Parallel transport of u from x to y."""
+    return gyration(y, -x, u) * (lambda_(x) / lambda_(y))
+
+
+def mobius_mul(x, t):
+    n = x.norm(dim=-1, p=2, keepdim=True).clamp_min(MIN_NORM)
+    return tanh(t * arctanh(n)) * (x / n)
+
+
+def get_midpoint_o(x):
+    return mobius_mul(x, 0.5)
+
+
+class HyperbolicDistance:
+    """exp(-acosh(1 + 2|x-y|^2/((1-|x|^2)(1-|y|^2)))) on projected points (hpcs/distances/poincare.py:139-187)."""
+    is_inverted = False
+    normalize_embeddings = False
+    p = 2
+
+    def __call__(self, query_emb, ref_emb=None):
+        return self.compute_mat(query_emb, ref_emb)
+
+    def compute_mat(self, query_emb, ref_emb=None):
+        if ref_emb is None:
+            ref_emb = query_emb
+        if query_emb.dim() == 3:
+            return torch.stack([self.compute_mat(q, r) for q, r in zip(query_emb, ref_emb)])
+        if query_emb.dim() != 2:
+            raise ValueError("Distance implemented only for tensors of rank 2 and 3")
+        x, y = query_emb.detach().contiguous().float(), ref_emb.detach().contiguous().float()
+        out = torch.empty(x.shape[0], y.shape[0], device=x.device, dtype=torch.float32)
+        _lib.call("hpcs_hyperbolic_sim_mat", x, y, x.shape[0], y.shape[0], x.shape[1], out)
+        return out
+
+    def pairwise_distance(self, query_emb, ref_emb):
+        x, y = project(query_emb), project(ref_emb)
+        xy = torch.nn.functional.pairwise_distance(x, y, p=2) ** 2
+        xx = 1 - torch.norm(x, dim=-1, p=2) ** 2
+        yy = 1 - torch.norm(y, dim=-1, p=2) ** 2
+        return torch.exp(-torch.acosh(1 + 2 * (xy / (xx * yy))))

@@ -1,0 +1,214 @@
+"""Mirror of hpcs/loss/ultrametric_loss.py:16-143 (MetricHyperbolicLoss) on HIP kernels.
+
+compute_loss(x_euclidean, x_poincare, labels) -> {"loss_hyp": {"losses": t}, "loss_metric": {"losses": t}}.
+
+What differs in HOW (DESIGN.md "Loss"):
+  * the (B*N)^2 cosine matrix is never built: the miner and the HypHC term gather row dots, and
+    mat_sim.mean() is evaluated in closed form 0.5 + 0.5*|sum_i x_hat_i|^2 / M^2;
+  * the LCA distance of two points on the same diameter-scaled sphere is evaluated from their similarity in
+    closed form (fp64 scalars) instead of the reference's cancellation-bound fp32 reflections;
+  * the number of mined triplets stays on the device (no host sync inside the step).
+PML (absent) behaviour restated here: CosFaceLoss = normalised-weights softmax with cos-margin 0.35, scale 2,
+mean reduction; parity unpinned.
+"""
+from typing import Union
+
+import torch
+
+from .. import _lib
+from ..distances import CosineSimilarity
+from ..miner.loss_and_miner_utils import TripletPlan
+from ..miner.triplet_margin_loss import TripletMarginLoss
+from ..miner.triplet_margin_miner import RandomTripletMarginMiner
+
+call = _lib.call
+
+
+class L2RowsFn(torch.autograd.Function):
+    """x [M,E] -> x / max(|x|, 1e-12)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous().float()
+        xn = torch.empty_like(x)
+        inv = torch.empty(x.shape[0], device=x.device, dtype=torch.float32)
+        call("hpcs_l2_rows_fwd", x, x.shape[0], x.shape[1], xn, inv)
+        ctx.save_for_backward(xn, inv)
+        return xn
+
+    @staticmethod
+    def backward(ctx, g):
+        xn, inv = ctx.saved_tensors
+        gx = torch.empty_like(xn)
+        call("hpcs_l2_rows_bwd", xn, inv, g.contiguous().float(), xn.shape[0], xn.shape[1], gx, 0)
+        return gx
+
+
+class HypHCFn(torch.autograd.Function):
+    """mean over mined triplets of sum(w) - sum(w*softmax(d/temp)), plus the closed-form mean similarity."""
+
+    @staticmethod
+    def forward(ctx, xn, scale, a, p, n, count, temperature):
+        M, E = xn.shape
+        dev = xn.device
+        loss_sum = torch.empty(1, dtype=torch.float64, device=dev)
+        call("hpcs_hyphc_fwd", xn, E, a, p, n, count, a.numel(), scale, temperature, loss_sum)
+        colsum = torch.empty(E, dtype=torch.float64, device=dev)
+        call("hpcs_colsum", xn, M, E, colsum)
+        mean_sim = 0.5 + 0.5 * (colsum * colsum).sum() / float(M * M)
+        out = loss_sum[0] / count[0].double() + mean_sim
+        ctx.save_for_backward(xn, scale, a, p, n, count, colsum)
+        ctx.temperature = temperature
+        return out.float()
+
+    @staticmethod
+    def backward(ctx, g):
+        xn, scale, a, p, n, count, colsum = ctx.saved_tensors
+        M, E = xn.shape
+        g32 = g.reshape(1).contiguous().float()
+        # d mean_sim / d xn_i = colsum / M^2 (same row for every i)
+        gxn = ((colsum / float(M * M)).float() * g32).unsqueeze(0).repeat(M, 1).contiguous()
+        gscale = torch.empty(1, dtype=torch.float64, device=xn.device)
+        call("hpcs_hyphc_bwd", xn, E, a, p, n, count, a.numel(), scale, ctx.temperature, g32, gxn, gscale)
+        return gxn, gscale.float().view_as(scale), None, None, None, None, None
+
+
+class CosFaceFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xn, wn, labels, margin, scale):
+        M, E = xn.shape
+        C = wn.shape[0]
+        logits = torch.empty(M, C, device=xn.device, dtype=torch.float32)
+        rows = torch.empty(M, device=xn.device, dtype=torch.float32)
+        call("hpcs_cosface_fwd", xn, wn, labels, M, E, C, margin, scale, logits, rows)
+        ctx.save_for_backward(xn, wn, labels, logits, rows)
+        ctx.scale = scale
+        ctx.mark_non_differentiable(logits)
+        mean = torch.empty(1, device=xn.device, dtype=torch.float32)
+        call("hpcs_rowsum", rows, 1, M, 1.0 / M, mean)
+        return mean[0], logits
+
+    @staticmethod
+    def backward(ctx, g, _glogits):
+        xn, wn, labels, logits, rows = ctx.saved_tensors
+        M, E = xn.shape
+        C = wn.shape[0]
+        gxn = torch.zeros_like(xn)
+        gwn = torch.empty_like(wn)
+        call("hpcs_cosface_bwd", xn, wn, labels, logits, rows, M, E, C, ctx.scale, g.reshape(1).contiguous().float(), gxn, gwn)
+        return gxn, gwn, None, None, None
+
+
+class CosFaceLoss(torch.nn.Module):
+    """PML CosFaceLoss(num_classes, embedding_size, margin, scale): W [E,C] ~ N(0,1), mean cross entropy."""
+
+    def __init__(self, num_classes, embedding_size, margin=0.35, scale=64):
+        super().__init__()
+        self.num_classes = num_classes
+        self.embedding_size = embedding_size
+        self.margin = margin
+        self.scale = scale
+        self.W = torch.nn.Parameter(torch.Tensor(embedding_size, num_classes))
+        torch.nn.init.normal_(self.W)
+
+    def logits_and_loss(self, embeddings, labels, xn=None):
+        if xn is None:
+            xn = L2RowsFn.apply(embeddings)
+        wn = L2RowsFn.apply(self.W.t())
+        return CosFaceFn.apply(xn, wn, labels.reshape(-1).to(torch.int64).contiguous(), float(self.margin),
+                               float(self.scale))
+
+    def forward(self, embeddings, labels, xn=None):
+        return self.logits_and_loss(embeddings, labels, xn)[0]
+
+
+class MetricHyperbolicLoss(torch.nn.Module):
+    def __init__(self, margin: float = 1.0, t_per_anchor: int = 50, fraction: float = 1.2,
+                 scale: Union[float, torch.Tensor, torch.nn.Parameter] = 1e-3, temperature: float = 0.05,
+                 anneal_factor: float = 0.5, num_class: int = 4, embedding_size: int = 4, cosface: bool = True,
+                 miner: bool = False, rng: str = "host"):
+        super().__init__()
+        self.margin = margin
+        self.t_per_anchor = t_per_anchor
+        self.fraction = fraction
+        self.scale = scale
+        self.temperature = temperature
+        self.anneal_factor = anneal_factor
+        self.num_class = num_class
+        self.embedding_size = embedding_size
+        self.cosface = cosface
+        self.miner = miner
+        self.distance_sim = CosineSimilarity()
+        if self.miner:
+            self.hyp_miner = RandomTripletMarginMiner(distance=self.distance_sim, margin=0, t_per_anchor=t_per_anchor,
+                                                      fraction=fraction, type_of_triplets="easy", rng=rng)
+        if self.cosface:
+            self.loss_cosface = CosFaceLoss(num_classes=num_class, embedding_size=embedding_size, margin=0.35, scale=2)
+        else:
+            self.triplet_miner = RandomTripletMarginMiner(distance=self.distance_sim, margin=margin,
+                                                          t_per_anchor=t_per_anchor, fraction=fraction,
+                                                          type_of_triplets="semihard", rng=rng)
+            self.loss_triplet = TripletMarginLoss(distance=self.distance_sim, margin=margin)
+        self.last_triplets = None
+
+    # ---- pieces ------------------------------------------------------------------------------------------
+    def _scale_tensor(self, like):
+        s = self.scale
+        if not torch.is_tensor(s):
+            s = torch.tensor([float(s)], device=like.device)
+        return s.reshape(1) if s.numel() == 1 else s
+
+    def get_triplets(self, n_samples, device):
+        """Miner-less fallback (ultrametric_loss.py:42-55): all pairs x t_per_anchor random thirds (host RNG)."""
+        ij = torch.combinations(torch.arange(n_samples), r=2).repeat_interleave(self.t_per_anchor, dim=0)
+        k = torch.randint(n_samples, (ij.shape[0],), dtype=torch.long)
+        keep = (ij[:, 0] != k) & (ij[:, 1] != k)
+        a, p, n = ij[keep, 0].to(device), ij[keep, 1].to(device), k[keep].to(device)
+        return a, p, n, torch.full((1,), a.numel(), dtype=torch.int64, device=device)
+
+    def compute_hyp(self, x_poincare, labels, plan=None, triplets=None, xn=None):
+        if xn is None:
+            xn = L2RowsFn.apply(x_poincare)
+        if triplets is None:
+            if self.miner:
+                triplets = self.hyp_miner.mine_device(x_poincare, labels, plan=plan, xn=xn.detach())
+            else:
+                triplets = self.get_triplets(x_poincare.shape[0], x_poincare.device)
+        a, p, n, count = triplets
+        self.last_triplets = triplets
+        scale = self._scale_tensor(xn)
+        return HypHCFn.apply(xn, scale, a, p, n, count, float(self.temperature))
+
+    def get_logits(self, embeddings, labels):
+        if not hasattr(self, "loss_cosface"):
+            raise ValueError("Cannot get logits since this class doesn't use any CosFaceLoss")
+        with torch.no_grad():
+            return self.loss_cosface.logits_and_loss(embeddings, labels)[1]
+
+    def compute_loss(self, x_euclidean, x_poincare, labels, *args, plan=None, plan_metric=None):
+        if not x_poincare.is_cuda:
+            raise _lib.HpcsNativeError("hpcs_amd losses need HIP-device tensors (there is no CPU fallback)")
+        labels = labels.reshape(-1)
+        xn = L2RowsFn.apply(x_poincare)
+        loss_hyperbolic = self.compute_hyp(x_poincare, labels, plan=plan, xn=xn)
+        if self.cosface:
+            loss_metric = self.loss_cosface(x_poincare, labels.long(), xn=xn)
+        else:
+            a, p, n, count = self.triplet_miner.mine_device(x_poincare, labels, plan=plan_metric or plan, xn=xn.detach())
+            loss_metric = self.loss_triplet(x_poincare, labels, (a, p, n), count=count)
+        return {"loss_hyp": {"losses": loss_hyperbolic}, "loss_metric": {"losses": loss_metric}}
+
+    def make_plan(self, labels_cpu_or_counts):
+        """Per-class sampling plan from host-side labels (call before the forward pass: no mid-step sync)."""
+        t = labels_cpu_or_counts
+        counts = torch.bincount(t.reshape(-1).to(torch.int64).cpu())
+        return TripletPlan(counts, self.t_per_anchor, self.fraction)
+
+    def anneal_temperature(self):
+        self.temperature *= min(max(float(self.anneal_factor), 0.2), 1.0)
+        return self.temperature
+
+    def normalize_embeddings(self, embeddings):
+        """Unit rows times clamp(scale, 1e-4, 1) (ultrametric_loss.py:139-143)."""
+        s = self._scale_tensor(embeddings)
+        return L2RowsFn.apply(embeddings) * torch.clamp(s, 1e-4, 1)

@@ -1,0 +1,120 @@
+"""Mirror of hpcs/nn/dgcnn/utils/vn_layers.py on HIP kernels.
+
+Same constructor signatures and state-dict names (map_to_feat / map_to_dir / batchnorm.bn.*); the torch
+sub-modules are parameter containers only -- forward runs hpcs_amd.ops (fused GEMM + VN kernels).
+"""
+import torch
+import torch.nn as nn
+
+from .... import ops
+
+EPS = 1e-6
+
+
+def _flat(x):
+    """[B,C,3,*S] view with all trailing dims kept (kernels see L = prod(S))."""
+    if x.dim() < 3 or x.size(2) != 3:
+        raise ValueError("vector-neuron features must have shape [B, C, 3, ...]")
+    return x
+
+
+class VNLinear(nn.Module):                                     # vn_layers.py:13-24
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.map_to_feat = nn.Linear(in_channels, out_channels, bias=False)
+
+    def forward(self, x):
+        return ops.chan_mix(_flat(x), self.map_to_feat.weight)
+
+
+class VNLeakyReLU(nn.Module):                                  # vn_layers.py:27-45
+    def __init__(self, in_channels, share_nonlinearity=False, negative_slope=0.2):
+        super().__init__()
+        self.map_to_dir = nn.Linear(in_channels, 1 if share_nonlinearity else in_channels, bias=False)
+        self.negative_slope = negative_slope
+        self.register_buffer("_eye", torch.eye(in_channels), persistent=False)
+
+    def forward(self, x):
+        return ops.vn_layer(_flat(x), self._eye, self.map_to_dir.weight, None, None, None, None, False,
+                            slope=self.negative_slope, flags=ops.VN_LRELU)
+
+
+class VNBatchNorm(nn.Module):                                  # vn_layers.py:112-132
+    def __init__(self, num_features, dim):
+        super().__init__()
+        self.dim = dim
+        if dim == 3 or dim == 4:
+            self.bn = nn.BatchNorm1d(num_features)
+        elif dim == 5:
+            self.bn = nn.BatchNorm2d(num_features)
+        self.register_buffer("_eye", torch.eye(num_features), persistent=False)
+
+    def forward(self, x):
+        bn = self.bn
+        training = self.training or not bn.track_running_stats
+        out = ops.vn_layer(_flat(x), self._eye, None, bn.weight, bn.bias, bn.running_mean, bn.running_var, training,
+                           flags=ops.VN_BN)
+        if training and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        return out
+
+
+class VNLinearLeakyReLU(nn.Module):                            # vn_layers.py:48-77
+    def __init__(self, in_channels, out_channels, dim=5, share_nonlinearity=False, negative_slope=0.2):
+        super().__init__()
+        self.dim = dim
+        self.negative_slope = negative_slope
+        self.map_to_feat = nn.Linear(in_channels, out_channels, bias=False)
+        self.batchnorm = VNBatchNorm(out_channels, dim=dim)
+        self.map_to_dir = nn.Linear(in_channels, 1 if share_nonlinearity else out_channels, bias=False)
+
+    def forward(self, x, pool_k=0):
+        """pool_k>0 additionally averages over the trailing dim of size pool_k (fused mean_pool)."""
+        bn = self.batchnorm.bn
+        out = ops.vn_layer(_flat(x), self.map_to_feat.weight, self.map_to_dir.weight, bn.weight, bn.bias, bn.running_mean,
+                           bn.running_var, self.training, slope=self.negative_slope, pool_k=pool_k)
+        if self.training:
+            bn.num_batches_tracked.add_(1)
+        return out
+
+
+class VNMaxPool(nn.Module):                                    # vn_layers.py:135-149
+    def __init__(self, in_channels):
+        super().__init__()
+        self.map_to_dir = nn.Linear(in_channels, in_channels, bias=False)
+
+    def forward(self, x):
+        d = ops.chan_mix(x.detach(), self.map_to_dir.weight.detach())
+        return ops.VNMaxPoolFn.apply(x, d)
+
+
+def mean_pool(x, dim=-1, keepdim=False):                       # vn_layers.py:152-153
+    if dim not in (-1, x.dim() - 1):
+        return x.mean(dim=dim, keepdim=keepdim)
+    out = ops.RowMeanFn.apply(x)
+    return out.unsqueeze(-1) if keepdim else out
+
+
+class VNStdFeature(nn.Module):                                 # vn_layers.py:156-205
+    def __init__(self, in_channels, dim=4, normalize_frame=False, share_nonlinearity=False, negative_slope=0.2):
+        super().__init__()
+        if normalize_frame:
+            raise NotImplementedError("normalize_frame=True is never used on the HPCS path (vn_dgcnn_partseg.py:39)")
+        if dim != 4:
+            raise NotImplementedError("only dim=4 is used on the HPCS path")
+        self.dim = dim
+        self.normalize_frame = normalize_frame
+        self.vn1 = VNLinearLeakyReLU(in_channels, in_channels // 2, dim=dim, share_nonlinearity=share_nonlinearity,
+                                     negative_slope=negative_slope)
+        self.vn2 = VNLinearLeakyReLU(in_channels // 2, in_channels // 4, dim=dim, share_nonlinearity=share_nonlinearity,
+                                     negative_slope=negative_slope)
+        self.vn_lin = nn.Linear(in_channels // 4, 3, bias=False)
+
+    def frame(self, x):
+        z = self.vn2(self.vn1(x))
+        z = ops.chan_mix(z, self.vn_lin.weight)        # [B,3,3,N]
+        return z.transpose(1, 2).contiguous()
+
+    def forward(self, x):
+        z0 = self.frame(x)
+        return ops.FrameProjectFn.apply(x, z0), z0

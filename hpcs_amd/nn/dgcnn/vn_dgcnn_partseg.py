@@ -1,0 +1,123 @@
+"""VN_DGCNN_partseg on gfx950 kernels -- drop-in for hpcs/nn/dgcnn/vn_dgcnn_partseg.py:7-104.
+
+Same constructor, same state-dict keys (conv1.map_to_feat.weight, conv8.0.weight, bn8.* aliases ...), same
+forward contract: x [B,3,N] fp32, l [B,num_categories] one-hot -> [B,N,out_features].
+
+Differences in HOW (not what) it computes (DESIGN.md "Extractor"):
+  * kNN is the fused score+top-k kernel (no N x N matrix);
+  * mean_pool is fused into the last VN layer of each EdgeConv block;
+  * conv8's 2110 channels that are constant over N (global max feature + category code) are applied as a
+    per-cloud row bias instead of being repeated N times (vn_dgcnn_partseg.py:92-95).
+"""
+import torch
+import torch.nn as nn
+
+from ... import ops
+from .utils.vn_layers import VNLinearLeakyReLU, VNMaxPool, VNStdFeature, mean_pool
+from .utils.vn_dgcnn_util import get_graph_feature
+
+
+class VN_DGCNN_partseg(nn.Module):
+    def __init__(self, in_channels, out_features, k, dropout, pooling, num_categories):
+        super().__init__()
+        self.in_channels = in_channels
+        self.out_features = out_features
+        self.k = k
+        self.dropout = dropout
+        self.pooling = pooling
+        self.num_categories = num_categories
+        c, g = 64 // 3, 1024 // 3
+
+        head_bn = {7: 64, 8: 256, 9: 256, 10: 128, 11: out_features}
+        for n, ch in head_bn.items():
+            setattr(self, f"bn{n}", nn.BatchNorm1d(ch))
+
+        for i, (cin, cout) in enumerate(((2, c), (c, c), (2 * c, c), (c, c), (2 * c, c)), start=1):
+            setattr(self, f"conv{i}", VNLinearLeakyReLU(cin, cout))
+
+        if pooling == "max":
+            for i in (1, 2, 3):
+                setattr(self, f"pool{i}", VNMaxPool(c))
+        elif pooling == "mean":
+            self.pool1 = self.pool2 = self.pool3 = mean_pool
+
+        self.conv6 = VNLinearLeakyReLU(3 * c, g, dim=4, share_nonlinearity=True)
+        self.std_feature = VNStdFeature(2 * g, dim=4, normalize_frame=False)
+
+        def head(cin, cout, bn, act=True):
+            layers = [nn.Conv1d(cin, cout, kernel_size=1, bias=False), bn]
+            if act:
+                layers.append(nn.LeakyReLU(negative_slope=0.2))
+            return nn.Sequential(*layers)
+
+        glob_ch = 2 * g * 3 + 64                     # 2046 invariant global + 64 category = 2110
+        self._glob_ch = glob_ch
+        self.conv8 = head(glob_ch + 3 * c * 3, 256, self.bn8)          # 2299 -> 256
+        self.conv7 = head(num_categories, 64, self.bn7)
+        self.dp1 = nn.Dropout(p=dropout)
+        self.conv9 = head(256, 256, self.bn9)
+        self.dp2 = nn.Dropout(p=dropout)
+        self.conv10 = head(256, 128, self.bn10)
+        self.conv11 = head(128, out_features, self.bn11, act=False)
+
+    # ---- helpers -----------------------------------------------------------------------------------------
+    def _edge_block(self, h, convs, pool):
+        e = get_graph_feature(h, k=self.k)
+        for conv in convs[:-1]:
+            e = conv(e)
+        if self.pooling == "mean":
+            return convs[-1](e, pool_k=self.k)            # fused mean over the k neighbours
+        return pool(convs[-1](e))
+
+    def _head(self, seq, x, rowbias=None, mask=None):
+        conv, bn = seq[0], seq[1]
+        y = ops.chan_mix(x, conv.weight[:, :, 0], rowbias)
+        slope = 0.2 if len(seq) > 2 else 1.0
+        out = ops.bn_act(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training, slope, mask)
+        if self.training:
+            bn.num_batches_tracked.add_(1)
+        return out
+
+    def _drop_mask(self, like, p, given):
+        if given is not None:
+            return given
+        if not self.training or p <= 0.0:
+            return None
+        return torch.empty_like(like).bernoulli_(1.0 - p).div_(1.0 - p)
+
+    # ---- forward -----------------------------------------------------------------------------------------
+    def forward(self, x, l, drop_masks=None):
+        """drop_masks=(m1,m2): optional already-scaled dropout multipliers [B,256,N] (parity tests)."""
+        if not x.is_cuda:
+            raise RuntimeError("hpcs_amd.VN_DGCNN_partseg runs on a HIP device only (no CPU fallback)")
+        B, N = x.size(0), x.size(2)
+        h = x.unsqueeze(1)
+
+        x1 = self._edge_block(h, (self.conv1, self.conv2), self.pool1)
+        x2 = self._edge_block(x1, (self.conv3, self.conv4), self.pool2)
+        x3 = self._edge_block(x2, (self.conv5,), self.pool3)
+        x123 = torch.cat((x1, x2, x3), dim=1)                                   # [B,63,3,N]
+
+        g = self.conv6(x123)                                                    # [B,341,3,N]
+        g = ops.ConcatMeanFn.apply(g)                                           # [B,682,3,N]
+        z0 = self.std_feature.frame(g)                                          # [B,3,3,N]
+        g_std = ops.FrameProjectFn.apply(g, z0)
+        loc = ops.FrameProjectFn.apply(x123, z0).view(B, -1, N)                 # [B,189,N]
+        glob = ops.RowMaxFn.apply(g_std.view(B, -1, N))                         # [B,2046]
+
+        cat = self._head(self.conv7, l.view(B, -1, 1).float())                  # [B,64,1]
+        vec = torch.cat((glob, cat.view(B, -1)), dim=1)                         # [B,2110]
+
+        W8 = self.conv8[0].weight[:, :, 0]
+        bias8 = ops.chan_mix(vec.unsqueeze(-1), W8[:, :self._glob_ch]).view(B, -1)          # [B,256]
+        y8 = ops.chan_mix(loc, W8[:, self._glob_ch:], bias8)
+        bn = self.bn8
+        m1 = self._drop_mask(y8, self.dropout, None if drop_masks is None else drop_masks[0])
+        hh = ops.bn_act(y8, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training, 0.2, m1)
+        if self.training:
+            bn.num_batches_tracked.add_(1)
+        m2 = self._drop_mask(hh, self.dropout, None if drop_masks is None else drop_masks[1])
+        hh = self._head(self.conv9, hh, mask=m2)
+        hh = self._head(self.conv10, hh)
+        hh = self._head(self.conv11, hh)
+        return hh.transpose(1, 2)

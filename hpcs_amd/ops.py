@@ -1,0 +1,384 @@
+"""torch.autograd.Functions over the C ABI (include/hpcs_mi355x.h).
+
+Host-side glue only: shape checks, output allocation from torch's caching allocator, weight
+re-layout, and the forward/backward call sequences.  All arithmetic runs in the gfx950 kernels.
+"""
+import torch
+
+from . import _lib
+
+call = _lib.call
+VN_BN, VN_LRELU = 1, 2
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.HpcsNativeError("hpcs_amd operators need HIP-device tensors (there is no CPU fallback)")
+
+
+def _f32c(t):
+    return t.contiguous() if t.dtype == torch.float32 else t.float().contiguous()
+
+
+def _pad4(n):
+    return (n + 3) // 4 * 4
+
+
+def _as_At(W):
+    """[M,K] weights -> K-major operand [K, pad4(M)] for hpcs_gemm_tn (computes W @ X)."""
+    M, K = W.shape
+    At = torch.zeros(K, _pad4(M), device=W.device, dtype=torch.float32)
+    At[:, :M] = W.t()
+    return At
+
+
+def _pad_cols(W):
+    """[M,K] -> [M, pad4(K)] (operand of the data-grad GEMM W^T @ G)."""
+    M, K = W.shape
+    if K % 4 == 0:
+        return W.contiguous()
+    P = torch.zeros(M, _pad4(K), device=W.device, dtype=torch.float32)
+    P[:, :K] = W
+    return P
+
+
+# ------------------------------------------------------------------------------------------------ raw GEMMs
+def gemm_WX(W, X, nb, K, Nc, rowbias=None, out=None, accumulate=False):
+    """out[b] (M x Nc) = W (M x K) @ X[b] (K x Nc); X / out are [nb, K, Nc] / [nb, M, Nc] views of contiguous data."""
+    M = W.shape[0]
+    if out is None:
+        out = torch.empty(nb * M * Nc, device=X.device, dtype=torch.float32)
+    At = _as_At(W)
+    call("hpcs_gemm_tn", At, At.shape[1], X, Nc, K * Nc, 0, out, Nc, M * Nc, 0, M, Nc, K, nb, 1, rowbias,
+         1 if accumulate else 0)
+    return out
+
+
+def gemm_WtG(W, G, nb, M, Nc, out=None, accumulate=False):
+    """out[b] (K x Nc) = W^T (K x M) @ G[b] (M x Nc)."""
+    K = W.shape[1]
+    if out is None:
+        out = torch.empty(nb * K * Nc, device=G.device, dtype=torch.float32)
+    Wp = _pad_cols(W)
+    call("hpcs_gemm_tn", Wp, Wp.shape[1], G, Nc, M * Nc, 0, out, Nc, K * Nc, 0, K, Nc, M, nb, 1, None,
+         1 if accumulate else 0)
+    return out
+
+
+def gemm_GXt(G, X, nb, M, K, Nc):
+    """dW (M x K) = sum_b G[b] (M x Nc) @ X[b]^T (K x Nc)."""
+    nbytes = call("hpcs_gemm_nt_workspace", M, K, Nc, nb, 1)
+    ws = torch.empty(nbytes // 4 + 4, device=G.device, dtype=torch.float32)
+    dW = torch.empty(M, K, device=G.device, dtype=torch.float32)
+    call("hpcs_gemm_nt", G, Nc, M * Nc, 0, X, Nc, K * Nc, 0, M, K, Nc, nb, 1, dW, K, 0, ws, nbytes)
+    return dW
+
+
+# ------------------------------------------------------------------------------------------------ a1 / a2
+def knn(x, k):
+    _need_cuda(x)
+    if x.dim() != 3:
+        raise ValueError("knn expects x of shape [B, D, N]")
+    x = _f32c(x.detach())
+    B, D, N = x.shape
+    if not 0 < k <= N:
+        raise ValueError(f"k={k} must be in 1..N={N}")
+    idx = torch.empty(B, N, k, dtype=torch.int64, device=x.device)
+    call("hpcs_knn", x, B, D, N, k, idx)
+    return idx
+
+
+class EdgeGatherFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, idx):
+        B, C, three, N = x.shape
+        k = idx.shape[-1]
+        x = _f32c(x)
+        idx = idx.contiguous()
+        out = torch.empty(B, 2 * C, 3, N, k, device=x.device, dtype=torch.float32)
+        call("hpcs_edge_gather_fwd", x, idx, B, C, N, k, out)
+        ctx.save_for_backward(idx)
+        ctx.dims = (B, C, N, k)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        B, C, N, k = ctx.dims
+        gx = torch.empty(B, C, 3, N, device=g.device, dtype=torch.float32)
+        call("hpcs_edge_gather_bwd", _f32c(g), idx, B, C, N, k, gx)
+        return gx, None
+
+
+# ------------------------------------------------------------------------------------------------ channel mix
+class ChanMixFn(torch.autograd.Function):
+    """y[b,o,...] = sum_c W[o,c] x[b,c,...] (+ rowbias[b,o])  (nn.Linear over dim 1; Conv1d k=1)."""
+
+    @staticmethod
+    def forward(ctx, x, W, rowbias=None):
+        x = _f32c(x)
+        W = _f32c(W)
+        B, K = x.shape[0], x.shape[1]
+        Nc = x[0, 0].numel()
+        M = W.shape[0]
+        rb = _f32c(rowbias) if rowbias is not None else None
+        y = gemm_WX(W, x, B, K, Nc, rowbias=rb).view(B, M, *x.shape[2:])
+        ctx.save_for_backward(x, W)
+        ctx.has_bias = rowbias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W = ctx.saved_tensors
+        g = _f32c(g)
+        B, K = x.shape[0], x.shape[1]
+        Nc = x[0, 0].numel()
+        M = W.shape[0]
+        gx = gW = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = gemm_WtG(W, g, B, M, Nc).view_as(x)
+        if ctx.needs_input_grad[1]:
+            gW = gemm_GXt(g, x, B, M, K, Nc)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = torch.empty(B, M, device=g.device)
+            call("hpcs_rowsum", g, B * M, Nc, 1.0, gb)
+        return gx, gW, gb
+
+
+def chan_mix(x, W, rowbias=None):
+    _need_cuda(x, W)
+    return ChanMixFn.apply(x, W, rowbias)
+
+
+# ------------------------------------------------------------------------------------------------ a3
+class VNLayerFn(torch.autograd.Function):
+    """p = Wf x ; [VNBatchNorm] ; [VN-LeakyReLU with d = Wd x] ; [mean over pool_k consecutive positions].
+
+    x [B,Cin,3,*S] -> [B,Cout,3,*S] (or [B,Cout,3,S0] when pool_k = S1 > 0).
+    One stacked GEMM produces PD = [Wf;Wd] x; backward recomputes the point-wise state from PD.
+    """
+
+    @staticmethod
+    def forward(ctx, x, Wf, Wd, gamma, beta, rmean, rvar, training, slope, pool_k, flags):
+        x = _f32c(x)
+        B, Cin = x.shape[0], x.shape[1]
+        L = x[0, 0, 0].numel()
+        Cout = Wf.shape[0]
+        Cd = Wd.shape[0] if (Wd is not None and (flags & VN_LRELU)) else 0
+        Wcat = torch.cat([Wf, Wd], 0) if Cd else Wf
+        Wcat = _f32c(Wcat)
+        Ctot = Cout + Cd
+        PD = gemm_WX(Wcat, x, B, Cin, 3 * L)
+        dev = x.device
+        mean = rstd = None
+        if flags & VN_BN:
+            mean = torch.empty(Cout, device=dev)
+            rstd = torch.empty(Cout, device=dev)
+            sums = None
+            if training:
+                sums = torch.empty(2 * Cout, device=dev, dtype=torch.float64)
+                call("hpcs_vn_norm_stats", PD, B, Cout, Ctot, L, sums)
+            call("hpcs_bn_finalize", sums, Cout, B * L, BN_EPS, BN_MOMENTUM, rmean, rvar, mean, rstd, 1 if training else 0)
+        if pool_k:
+            out = torch.empty(B, Cout, 3, L // pool_k, device=dev)
+        else:
+            out = torch.empty(B, Cout, *x.shape[2:], device=dev)
+        call("hpcs_vn_apply_fwd", PD, mean, rstd, gamma, beta, B, Cout, Cd, L, pool_k, slope, flags, out)
+        ctx.save_for_backward(x, Wcat, PD, mean, rstd, gamma, beta)
+        ctx.cfg = (B, Cin, Cout, Cd, L, pool_k, slope, flags, bool(training))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, Wcat, PD, mean, rstd, gamma, beta = ctx.saved_tensors
+        B, Cin, Cout, Cd, L, pool_k, slope, flags, training = ctx.cfg
+        g = _f32c(g)
+        dev = g.device
+        Ctot = Cout + Cd
+        red = None
+        if flags & VN_BN:
+            red = torch.empty(2 * Cout, device=dev, dtype=torch.float64)
+            call("hpcs_vn_bwd_reduce", PD, g, mean, rstd, gamma, beta, B, Cout, Cd, L, pool_k, slope, flags, red)
+        GPD = torch.empty(B * Ctot * 3 * L, device=dev)
+        call("hpcs_vn_bwd_apply", PD, g, mean, rstd, gamma, beta, red, 1 if training else 0, B, Cout, Cd, L, pool_k, slope,
+             flags, GPD)
+        gx = gW = gWd = ggamma = gbeta = None
+        if ctx.needs_input_grad[0]:
+            gx = gemm_WtG(Wcat, GPD, B, Ctot, 3 * L).view_as(x)
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            gWcat = gemm_GXt(GPD, x, B, Ctot, Cin, 3 * L)
+            gW = gWcat[:Cout]
+            gWd = gWcat[Cout:] if Cd else None
+        if flags & VN_BN:
+            gbeta = red[:Cout].float()
+            ggamma = red[Cout:].float()
+        return gx, gW, gWd, ggamma, gbeta, None, None, None, None, None, None
+
+
+def vn_layer(x, Wf, Wd, gamma, beta, rmean, rvar, training, slope=0.2, pool_k=0, flags=VN_BN | VN_LRELU):
+    _need_cuda(x, Wf)
+    return VNLayerFn.apply(x, Wf, Wd, gamma, beta, rmean, rvar, training, slope, pool_k, flags)
+
+
+# ------------------------------------------------------------------------------------------------ Conv1d heads
+class BnActFn(torch.autograd.Function):
+    """BatchNorm1d over [B,C,L] (+ LeakyReLU(slope)) (* mask)."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, rmean, rvar, training, slope, mask):
+        y = _f32c(y)
+        B, C = y.shape[0], y.shape[1]
+        L = y[0, 0].numel()
+        dev = y.device
+        mean = torch.empty(C, device=dev)
+        rstd = torch.empty(C, device=dev)
+        sums = None
+        if training:
+            sums = torch.empty(2 * C, device=dev, dtype=torch.float64)
+            call("hpcs_bn_stats", y, B, C, L, sums)
+        call("hpcs_bn_finalize", sums, C, B * L, BN_EPS, BN_MOMENTUM, rmean, rvar, mean, rstd, 1 if training else 0)
+        out = torch.empty_like(y)
+        call("hpcs_bn_act_fwd", y, mean, rstd, gamma, beta, mask, B, C, L, slope, out)
+        ctx.save_for_backward(y, mean, rstd, gamma, beta, mask)
+        ctx.cfg = (B, C, L, slope, bool(training))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        y, mean, rstd, gamma, beta, mask = ctx.saved_tensors
+        B, C, L, slope, training = ctx.cfg
+        g = _f32c(g)
+        red = torch.empty(2 * C, device=g.device, dtype=torch.float64)
+        call("hpcs_bn_act_bwd_reduce", y, g, mean, rstd, gamma, beta, mask, B, C, L, slope, red)
+        gy = torch.empty_like(y)
+        call("hpcs_bn_act_bwd_apply", y, g, mean, rstd, gamma, beta, mask, red, 1 if training else 0, B, C, L, slope, gy)
+        return gy, red[C:].float(), red[:C].float(), None, None, None, None, None
+
+
+def bn_act(y, gamma, beta, rmean, rvar, training, slope=0.2, mask=None):
+    _need_cuda(y)
+    return BnActFn.apply(y, gamma, beta, rmean, rvar, training, slope, mask)
+
+
+# ------------------------------------------------------------------------------------------------ glue ops
+class ConcatMeanFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _f32c(x)
+        B, C, _, N = x.shape
+        out = torch.empty(B, 2 * C, 3, N, device=x.device)
+        call("hpcs_concat_mean_fwd", x, B, C, N, out)
+        ctx.dims = (B, C, N)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C, N = ctx.dims
+        gx = torch.empty(B, C, 3, N, device=g.device)
+        call("hpcs_concat_mean_bwd", _f32c(g), B, C, N, gx)
+        return gx
+
+
+class FrameProjectFn(torch.autograd.Function):
+    """einsum('bijm,bjkm->bikm', x [B,C,3,N], z [B,3,3,N])."""
+
+    @staticmethod
+    def forward(ctx, x, z):
+        x, z = _f32c(x), _f32c(z)
+        B, C, _, N = x.shape
+        out = torch.empty_like(x)
+        call("hpcs_frame_project_fwd", x, z, B, C, N, out)
+        ctx.save_for_backward(x, z)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, z = ctx.saved_tensors
+        B, C, _, N = x.shape
+        gx = torch.empty_like(x)
+        gz = torch.empty_like(z)
+        call("hpcs_frame_project_bwd", x, z, _f32c(g), B, C, N, gx, gz)
+        return gx, gz
+
+
+class RowMaxFn(torch.autograd.Function):
+    """max over the last dim (values only differentiable)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _f32c(x)
+        L = x.shape[-1]
+        rows = x.numel() // L
+        out = torch.empty(x.shape[:-1], device=x.device)
+        arg = torch.empty(rows, device=x.device, dtype=torch.int32)
+        call("hpcs_rowmax_fwd", x, rows, L, out, arg)
+        ctx.save_for_backward(arg)
+        ctx.shape = x.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (arg,) = ctx.saved_tensors
+        L = ctx.shape[-1]
+        rows = arg.numel()
+        gx = torch.empty(ctx.shape, device=g.device)
+        call("hpcs_rowmax_bwd", _f32c(g), arg, rows, L, gx)
+        return gx
+
+
+class RowMeanFn(torch.autograd.Function):
+    """mean over the last dim."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _f32c(x)
+        L = x.shape[-1]
+        rows = x.numel() // L
+        out = torch.empty(x.shape[:-1], device=x.device)
+        call("hpcs_rowsum", x, rows, L, 1.0 / L, out)
+        ctx.shape = x.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        L = ctx.shape[-1]
+        return (g / L).unsqueeze(-1).expand(ctx.shape)
+
+
+class RowSumFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _f32c(x)
+        L = x.shape[-1]
+        rows = x.numel() // L
+        out = torch.empty(x.shape[:-1], device=x.device)
+        call("hpcs_rowsum", x, rows, L, 1.0, out)
+        ctx.shape = x.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.unsqueeze(-1).expand(ctx.shape)
+
+
+class VNMaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, d):
+        x, d = _f32c(x), _f32c(d)
+        B, C, _, N, k = x.shape
+        out = torch.empty(B, C, 3, N, device=x.device)
+        arg = torch.empty(B, C, N, device=x.device, dtype=torch.int32)
+        call("hpcs_vn_maxpool_fwd", x, d, B, C, N, k, out, arg)
+        ctx.save_for_backward(arg)
+        ctx.dims = (B, C, N, k)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (arg,) = ctx.saved_tensors
+        B, C, N, k = ctx.dims
+        gx = torch.empty(B, C, 3, N, k, device=g.device)
+        call("hpcs_vn_maxpool_bwd", _f32c(g), arg, B, C, N, k, gx)
+        return gx, None

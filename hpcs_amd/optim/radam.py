@@ -1,0 +1,73 @@
+"""Mirror of hpcs/optim/radam.py:29-134 (Riemannian Adam applied to every parameter) as ONE fused HIP launch.
+
+Quirks of the reference that are kept: group["step"] is incremented twice per parameter
+(radam.py:116,133), so parameter i of a step uses the exponent 2*n_done+1; project() clips every row of every
+tensor to norm 1-4e-3; weight decay and egrad2rgrad mutate .grad in place.
+"""
+import ctypes
+
+import torch
+
+from .. import _lib
+
+
+class RAdam(torch.optim.Adam):
+    def _table(self, group, params):
+        """Device table: descriptors + row starts (rebuilt when the tensors or step sizes change)."""
+        import struct
+        b1, b2 = group["betas"]
+        lr = group["lr"]
+        blob = bytearray()
+        row_starts, rows_total = [], 0
+        for p in params:
+            st = self.state[p]
+            group["step"] += 1
+            t = group["step"]
+            step_size = lr * (1 - b2 ** t) ** 0.5 / (1 - b1 ** t)
+            group["step"] += 1
+            cols = p.shape[-1] if p.dim() > 0 else 1
+            rows = p.numel() // cols
+            blob += struct.pack("<QQQQqif", p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(),
+                                st["exp_avg_sq"].data_ptr(), rows, cols, step_size)
+            row_starts.append(rows_total)
+            rows_total += rows
+        row_starts.append(rows_total)
+        blob += struct.pack(f"<{len(row_starts)}q", *row_starts)
+        host = torch.frombuffer(blob, dtype=torch.uint8)
+        return host, rows_total
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            if "step" not in group:
+                group["step"] = 0
+            if group.get("amsgrad", False):
+                raise NotImplementedError("amsgrad is never enabled by HPCS (base_hyp_hc.py:143)")
+            params = []
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if p.grad.is_sparse:
+                    raise RuntimeError("Riemannian Adam does not support sparse gradients")
+                if not p.is_cuda:
+                    raise _lib.HpcsNativeError("hpcs_amd.optim.RAdam needs HIP-device parameters (no CPU fallback)")
+                if not (p.is_contiguous() and p.grad.is_contiguous()):
+                    raise _lib.HpcsNativeError("RAdam needs contiguous parameters and gradients")
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                params.append(p)
+            if not params:
+                continue
+            host, rows_total = self._table(group, params)
+            dev_table = host.to(params[0].device, non_blocking=False)
+            b1, b2 = group["betas"]
+            _lib.call("hpcs_radam_step", dev_table, len(params), rows_total, b1, b2, group["eps"], group["weight_decay"])
+            self._keep = dev_table     # keep the table alive until the kernel has consumed it
+        return loss

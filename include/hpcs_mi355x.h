@@ -189,8 +189,10 @@ int hpcs_hyphc_bwd(const float* xn, int E, const int64_t* a, const int64_t* p, c
 int hpcs_colsum(const float* xn, int64_t rows, int E, double* colsum, hpcs_stream_t stream);
 int hpcs_cosface_fwd(const float* xn, const float* wn, const int64_t* labels, int M, int E, int C, float margin,
                      float scale, float* logits, float* loss_rows, hpcs_stream_t stream);
-int hpcs_cosface_bwd(const float* xn, const float* wn, const int64_t* labels, const float* logits, int M, int E,
-                     int C, float scale, float gscale_over_M, float* gxn, float* gwn, hpcs_stream_t stream);
+/* bwd: gxn [M,E] is ACCUMULATED into, gwn [C,E] is overwritten; gloss = device scalar dL/d(mean loss) */
+int hpcs_cosface_bwd(const float* xn, const float* wn, const int64_t* labels, const float* logits,
+                     const float* loss_rows, int M, int E, int C, float scale, const float* gloss, float* gxn,
+                     float* gwn, hpcs_stream_t stream);
 int hpcs_triplet_margin_fwd(const float* xn, int E, const int64_t* a, const int64_t* p, const int64_t* n,
                             const int64_t* count, int64_t T_cap, float margin, double* sum_and_nnz,
                             hpcs_stream_t stream);

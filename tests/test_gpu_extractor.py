@@ -1,0 +1,290 @@
+"""GPU parity of the extractor path (a2-a7) against the reference's golden vectors and the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from _det import det_cloud, det_int, det_normalish, det_params, det_uniform
+from oracle import extractor as OE, hyperbolic as OH
+
+pytestmark = pytest.mark.gpu
+dev = "cuda"
+T = torch.from_numpy
+
+
+def close(a, b, rtol=1e-5, atol=1e-6):
+    a = a.detach().cpu().float()
+    b = (T(np.asarray(b)) if not torch.is_tensor(b) else b.detach().cpu()).float()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    torch.testing.assert_close(a, b, rtol=rtol, atol=atol)
+
+
+def relclose(a, b, tol):
+    a = a.detach().cpu().double()
+    b = (T(np.asarray(b)) if not torch.is_tensor(b) else b.detach().cpu()).double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = float((a - b).norm() / b.norm().clamp_min(1e-30))
+    assert err < tol, err
+
+
+def load(mod, seed):
+    sd = mod.state_dict()
+    mod.load_state_dict(det_params({k: tuple(v.shape) for k, v in sd.items()}, seed))
+    return mod.to(dev)
+
+
+@pytest.mark.parametrize("tag,C", [("c1", 1), ("c21", 21)])
+def test_get_graph_feature(golden, tag, C):
+    from hpcs_amd.nn.dgcnn.utils.vn_dgcnn_util import get_graph_feature
+    x = det_normalish((2, C, 3, 32), 20 + C)
+    close(get_graph_feature(x.to(dev), k=4), golden[f"ggf_{tag}"], rtol=0, atol=0)
+    idx = det_int((2, 32, 4), 23, 32)
+    xg = x.to(dev).requires_grad_(True)
+    y = get_graph_feature(xg, k=4, idx=idx.to(dev))
+    close(y, golden[f"ggf_{tag}_given_idx"], rtol=0, atol=0)
+    w = det_uniform(tuple(y.shape), 5)
+    (y * w.to(dev)).sum().backward()
+    xr = x.clone().requires_grad_(True)
+    (OE.graph_feature(xr, 4, idx=idx) * w).sum().backward()
+    close(xg.grad, xr.grad, rtol=1e-5, atol=1e-5)
+
+
+def test_vn_linear_leaky_relu_dim5(golden):
+    from hpcs_amd.nn.dgcnn.utils.vn_layers import VNLinearLeakyReLU
+    x5 = det_normalish((2, 6, 3, 16, 4), 30)
+    m = load(VNLinearLeakyReLU(6, 5), 31)
+    m.train()
+    xg = x5.to(dev).requires_grad_(True)
+    y = m(xg)
+    close(y, golden["vnllr5_train_out"], rtol=1e-4, atol=1e-5)
+    (y * det_uniform(tuple(y.shape), 32).to(dev)).sum().backward()
+    close(xg.grad, golden["vnllr5_train_gx"], rtol=1e-3, atol=1e-5)
+    for n_, p_ in m.named_parameters():
+        close(p_.grad, golden["vnllr5_train_g_" + n_], rtol=1e-3, atol=2e-5)
+    close(m.batchnorm.bn.running_mean, golden["vnllr5_train_rm"])
+    close(m.batchnorm.bn.running_var, golden["vnllr5_train_rv"])
+    assert int(m.batchnorm.bn.num_batches_tracked) == 1
+    m.eval()
+    close(m(x5.to(dev)), golden["vnllr5_eval_out"], rtol=1e-4, atol=1e-5)
+
+
+def test_vn_linear_leaky_relu_dim4_shared(golden):
+    from hpcs_amd.nn.dgcnn.utils.vn_layers import VNLinearLeakyReLU
+    x4 = det_normalish((2, 7, 3, 24), 33)
+    m = load(VNLinearLeakyReLU(7, 9, dim=4, share_nonlinearity=True), 34)
+    m.train()
+    xg = x4.to(dev).requires_grad_(True)
+    y = m(xg)
+    close(y, golden["vnllr4s_train_out"], rtol=1e-4, atol=1e-5)
+    (y * det_uniform(tuple(y.shape), 35).to(dev)).sum().backward()
+    close(xg.grad, golden["vnllr4s_train_gx"], rtol=1e-3, atol=1e-5)
+    for n_, p_ in m.named_parameters():
+        close(p_.grad, golden["vnllr4s_train_g_" + n_], rtol=1e-3, atol=2e-5)
+    m.eval()
+    close(m(x4.to(dev)), golden["vnllr4s_eval_out"], rtol=1e-4, atol=1e-5)
+
+
+def test_fused_mean_pool_matches_unfused():
+    from hpcs_amd.nn.dgcnn.utils.vn_layers import VNLinearLeakyReLU, mean_pool
+    x5 = det_normalish((2, 6, 3, 16, 4), 30).to(dev)
+    m = load(VNLinearLeakyReLU(6, 5), 31)
+    m.train()
+    xa = x5.clone().requires_grad_(True)
+    xb = x5.clone().requires_grad_(True)
+    ya = m(xa, pool_k=4)
+    yb = mean_pool(m(xb))
+    close(ya, yb, rtol=1e-5, atol=1e-6)
+    w = det_uniform(tuple(ya.shape), 3).to(dev)
+    (ya * w).sum().backward()
+    ga = m.map_to_feat.weight.grad.clone()
+    m.zero_grad()
+    (yb * w).sum().backward()
+    close(xa.grad, xb.grad, rtol=1e-4, atol=1e-6)
+    close(ga, m.map_to_feat.weight.grad, rtol=1e-4, atol=1e-5)
+
+
+def test_vn_batchnorm_pool_std(golden):
+    from hpcs_amd.nn.dgcnn.utils.vn_layers import VNBatchNorm, VNMaxPool, VNStdFeature, mean_pool, VNLinear, VNLeakyReLU
+    x5 = det_normalish((2, 6, 3, 16, 4), 30)
+    m = load(VNBatchNorm(6, dim=5), 36)
+    m.train()
+    close(m(x5.to(dev)), golden["vnbn5_train_out"], rtol=1e-4, atol=1e-5)
+    close(m.bn.running_mean, golden["vnbn5_train_rm"])
+    close(m.bn.running_var, golden["vnbn5_train_rv"])
+    m.eval()
+    close(m(x5.to(dev)), golden["vnbn5_eval_out"], rtol=1e-4, atol=1e-5)
+    m = load(VNMaxPool(6), 37)
+    close(m(x5.to(dev)), golden["vnmaxpool_out"], rtol=0, atol=0)
+    close(mean_pool(x5.to(dev)), golden["meanpool_out"])
+    x8 = det_normalish((2, 8, 3, 24), 38)
+    m = load(VNStdFeature(8, dim=4, normalize_frame=False), 39)
+    m.train()
+    xs, z0 = m(x8.to(dev))
+    close(xs, golden["vnstd_train_xstd"], rtol=1e-3, atol=1e-4)
+    close(z0, golden["vnstd_train_z0"], rtol=1e-3, atol=1e-4)
+    m.eval()
+    xs, z0 = m(x8.to(dev))
+    close(xs, golden["vnstd_eval_xstd"], rtol=1e-3, atol=1e-4)
+    close(z0, golden["vnstd_eval_z0"], rtol=1e-3, atol=1e-4)
+    # VNLinear / VNLeakyReLU (API completeness) against the oracle formulas
+    lin = load(VNLinear(6, 4), 41)
+    close(lin(x5.to(dev)), OE._chan_mix(lin.map_to_feat.weight.cpu(), x5), rtol=1e-5, atol=1e-5)
+    act = load(VNLeakyReLU(6), 42)
+    want = OE.vn_leaky(x5, OE._chan_mix(act.map_to_dir.weight.detach().cpu(), x5))
+    close(act(x5.to(dev)), want, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("E", [2, 32])
+def test_full_extractor_vs_reference(golden, E):
+    from hpcs_amd.nn.dgcnn import VN_DGCNN_partseg
+    net = VN_DGCNN_partseg(in_channels=3, out_features=E, k=10, dropout=0.0, pooling="mean", num_categories=16)
+    sd = det_params(OE.param_shapes(E, 16), 40 + E)
+    net.load_state_dict(sd, strict=True)          # the reference's state-dict keys load unchanged
+    net.to(dev)
+    x = det_cloud(4, 256, 50 + E)
+    lab = torch.eye(16)[det_int((4,), 51, 16)]
+    net.eval()
+    with torch.no_grad():
+        y = net(x.to(dev), lab.to(dev))
+    ref = T(golden[f"net_E{E}_eval_out"])
+    close(y, ref, rtol=1e-4, atol=3e-5 * float(ref.abs().max()))
+    net.train()
+    xg = x.to(dev).requires_grad_(True)
+    y = net(xg, lab.to(dev))
+    ref = T(golden[f"net_E{E}_train_out"])
+    close(y, ref, rtol=1e-4, atol=5e-5 * float(ref.abs().max()))
+    (y * det_uniform(tuple(y.shape), 52).to(dev)).sum().backward()
+    # Gradient tolerance: in train mode the fp32 REFERENCE's own gradients sit 0.4-1.4% (L2) from an fp64
+    # evaluation of the same graph (13 batch-norms, measured in DESIGN.md "Gradient conditioning"); the HIP
+    # path is held to the same band against the reference.
+    GT = 1.5e-2
+    relclose(xg.grad, golden[f"net_E{E}_train_gx"], GT)
+    checked = 0
+    for n_, p_ in net.named_parameters():
+        if f"net_E{E}_train_g_{n_}" in golden:
+            relclose(p_.grad, golden[f"net_E{E}_train_g_{n_}"], GT)
+            checked += 1
+        elif f"net_E{E}_train_gs_{n_}" in golden:
+            relclose(p_.grad.flatten()[::97], golden[f"net_E{E}_train_gs_{n_}"], GT)
+            gn = golden[f"net_E{E}_train_gn_{n_}"]
+            assert abs(float(p_.grad.norm()) - gn[0]) <= GT * gn[0]
+            checked += 1
+    assert checked >= 40
+    for name in ("conv1.batchnorm.bn.running_mean", "conv5.batchnorm.bn.running_var", "bn11.running_var"):
+        close(dict(net.named_buffers())[name], golden[f"net_E{E}_train_buf_{name}"], rtol=1e-4, atol=1e-6)
+
+
+def test_extractor_matches_oracle_with_dropout_masks_and_maxpool():
+    from hpcs_amd.nn.dgcnn import VN_DGCNN_partseg
+    for pooling in ("mean", "max"):
+        net = VN_DGCNN_partseg(3, 8, k=6, dropout=0.5, pooling=pooling, num_categories=4)
+        P = det_params(OE.param_shapes(8, 4, pooling=pooling), 77)
+        net.load_state_dict(P, strict=True)
+        net.to(dev).train()
+        x = det_cloud(3, 96, 78)
+        lab = torch.eye(4)[det_int((3,), 79, 4)]
+        masks = [(det_uniform((3, 256, 96), 80 + i) > 0).float() * 2.0 for i in range(2)]
+        y = net(x.to(dev), lab.to(dev), drop_masks=[m.to(dev) for m in masks])
+        Po = OE.resolve_aliases({k: v.clone() for k, v in P.items()})
+        want = OE.vn_dgcnn_partseg(x, lab, Po, k=6, training=True, pooling=pooling, drop_masks=masks,
+                                   knn_fn=OE.knn_exact)
+        close(y, want, rtol=1e-3, atol=1e-4 * float(want.abs().max()))
+
+
+def test_rotation_invariance():
+    """The reference's only test (test/test_rotation_invariance.py:41-73) as a property: SO(3) invariance in eval."""
+    from hpcs_amd.nn.dgcnn import VN_DGCNN_partseg
+    net = VN_DGCNN_partseg(3, 2, k=10, dropout=0.0, pooling="mean", num_categories=16)
+    net.load_state_dict(det_params(OE.param_shapes(2, 16), 42))
+    net.to(dev).eval()
+    x = det_cloud(1, 256, 90).to(dev)
+    lab = torch.eye(16)[[3]].to(dev)
+    q, _ = torch.linalg.qr(det_normalish((3, 3), 91).double())
+    if torch.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    R = q.float().to(dev)
+    with torch.no_grad():
+        y1 = net(x, lab)
+        y2 = net(torch.einsum("ij,bjn->bin", R, x).contiguous(), lab)
+    assert float((y1 - y2).abs().max()) < 1e-3 * float(y1.abs().max())
+
+
+def test_embedders(golden):
+    from hpcs_amd.nn.hyperbolic import ExpMap, MLPExpMap
+    u = det_normalish((6, 5, 32), 60)
+    u[0, 0] = 0.0
+    u[0, 1] *= 1e-9
+    u[1, 0] *= 40.0
+    ug = u.to(dev).requires_grad_(True)
+    y = ExpMap()(ug)
+    close(y, golden["expmap_out"])
+    (y * det_uniform(tuple(y.shape), 61).to(dev)).sum().backward()
+    close(ug.grad, golden["expmap_gu"], rtol=1e-4, atol=1e-6)
+    me = MLPExpMap(32, 8)
+    me.load_state_dict({"mlp.0.0.weight": det_uniform((8, 32), 62) * 0.3})
+    me.to(dev)
+    ug = u.to(dev).requires_grad_(True)
+    y = me(ug)
+    close(y, golden["mlpexpmap_out"], rtol=1e-4, atol=1e-6)
+    (y * det_uniform(tuple(y.shape), 63).to(dev)).sum().backward()
+    close(ug.grad, golden["mlpexpmap_gu"], rtol=1e-4, atol=1e-6)
+    close(me.mlp[0][0].weight.grad, golden["mlpexpmap_gw"], rtol=1e-4, atol=1e-5)
+
+
+def test_poincare_helpers(golden):
+    from hpcs_amd.utils import poincare as UP
+    from hpcs_amd.utils.math import arctanh
+    from hpcs_amd.distances import poincare as DP
+    a = det_normalish((64, 8), 70) * 0.3
+    b = det_normalish((64, 8), 71) * 0.3
+    a[0] = 0.0
+    big = det_normalish((16, 8), 72) * 3.0
+    close(UP.mobius_add(a.to(dev), b.to(dev)), golden["mobius_add_out"])
+    close(UP.project(torch.cat([a, big]).to(dev)), golden["project_out"])
+    close(UP.expmap_1(b.to(dev), a.to(dev)), golden["expmap_pu_out"])
+    close(UP.lambda_(a.to(dev)), golden["lambda_out"])
+    close(UP.hyp_dist_o(torch.cat([a, big * 0.33]).to(dev)), golden["hyp_dist_o_out"])
+    t = torch.tensor([-2.0, -1.0, -0.999995, -0.5, 0.0, 1e-8, 0.5, 0.99999, 0.999999, 1.0, 3.0])
+    tg = t.to(dev).requires_grad_(True)
+    y = arctanh(tg)
+    close(y, golden["artanh_out"], rtol=1e-6, atol=1e-9)
+    y.sum().backward()
+    close(tg.grad, golden["artanh_grad"], rtol=1e-6, atol=0)
+    w = det_normalish((64, 8), 73) * 0.2
+    close(DP.gyration(a.to(dev), b.to(dev), w.to(dev)), golden["gyration_out"])
+    close(DP.ptransp(a.to(dev), b.to(dev), w.to(dev)), golden["ptransp_out"])
+    close(DP.inner(a.to(dev), w.to(dev)), golden["inner_out"])
+    close(DP.egrad2rgrad(a.to(dev), w.clone().to(dev)), golden["egrad2rgrad_out"])
+    close(DP.mobius_mul((a + 1e-3).to(dev), 0.5), golden["mobius_mul_out"], rtol=1e-5, atol=1e-7)
+    # a15: HyperbolicDistance (never instantiated by the reference; checked against the oracle restatement)
+    x = det_normalish((20, 6), 74) * 0.4
+    yv = det_normalish((12, 6), 75) * 0.4
+    close(DP.HyperbolicDistance().compute_mat(x.to(dev), yv.to(dev)), OH.hyperbolic_similarity_mat(x, yv), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("si,s", list(enumerate((1e-4, 1e-3, 1e-2, 1e-1, 0.5, 0.9))))
+def test_hyp_lca(golden, si, s):
+    """Well-conditioned scales: match the reference.  Small scales: the reference's fp32 reflections are
+    cancellation-bound, so the bar is the fp64 evaluation, and being no worse than the reference."""
+    from hpcs_amd.distances import hyp_lca
+    da = torch.nn.functional.normalize(det_normalish((48, 32), 80 + si), dim=1)
+    db = torch.nn.functional.normalize(det_normalish((48, 32), 90 + si), dim=1)
+    a32, b32 = (da * s), (db * s)
+    truth = OH.hyp_lca(a32.double(), b32.double(), return_coord=False).float()
+    ref = T(golden[f"hyp_lca_s{si}_dist"])
+    ag = a32.to(dev).requires_grad_(True)
+    bg = b32.to(dev).requires_grad_(True)
+    d = hyp_lca(ag, bg, return_coord=False)
+    close(d, truth, rtol=2e-5, atol=0)
+    err_ours = float(((d.detach().cpu() - truth) / truth).abs().max())
+    err_ref = float(((ref - truth) / truth).abs().max())
+    assert err_ours <= max(err_ref, 2e-5)
+    if s >= 0.1:
+        close(d, ref, rtol=5e-5, atol=0)
+        close(hyp_lca(a32.to(dev), b32.to(dev), return_coord=True), golden[f"hyp_lca_s{si}_coord"], rtol=1e-3, atol=1e-6)
+    # gradient against autograd through the fp64 oracle
+    ad = a32.double().requires_grad_(True)
+    bd = b32.double().requires_grad_(True)
+    OH.hyp_lca(ad, bd, return_coord=False).sum().backward()
+    d.sum().backward()
+    relclose(ag.grad, ad.grad, 1e-4)
+    relclose(bg.grad, bd.grad, 1e-4)
