@@ -1,0 +1,182 @@
+"""GPU parity of the miner / loss / optimizer rows (a8-a14, RAdam) against the oracle and golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+from _det import det_int, det_normalish, det_uniform
+from oracle import hyperbolic as OH, metric as OM
+from test_oracle_golden import SAMPLER_CASES
+
+pytestmark = pytest.mark.gpu
+dev = "cuda"
+T = torch.from_numpy
+
+
+def close(a, b, rtol=1e-5, atol=1e-6):
+    a = a.detach().cpu().float()
+    b = (T(np.asarray(b)) if not torch.is_tensor(b) else b.detach().cpu()).float()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    torch.testing.assert_close(a, b, rtol=rtol, atol=atol)
+
+
+def relclose(a, b, tol):
+    a = a.detach().cpu().double()
+    b = (T(np.asarray(b)) if not torch.is_tensor(b) else b.detach().cpu()).double()
+    err = float((a - b).norm() / b.norm().clamp_min(1e-30))
+    assert err < tol, err
+
+
+@pytest.mark.parametrize("name", list(SAMPLER_CASES))
+@pytest.mark.parametrize("frac", [0.0, 1.2])
+def test_sampler_identical_to_reference(golden, name, frac):
+    """rng='host' consumes the CPU generator like the reference -> identical (a,p,n)."""
+    from hpcs_amd.miner.loss_and_miner_utils import get_balanced_random_triplet_indices
+    lab = SAMPLER_CASES[name]()
+    torch.manual_seed(1234)
+    a, p, n = get_balanced_random_triplet_indices(lab.to(dev), t_per_anchor=5, fraction=frac)
+    ref = golden[f"sampler_{name}_f{int(frac * 10)}_apn"].astype(np.int64)
+    assert np.array_equal(torch.stack([a, p, n]).cpu().numpy(), ref)
+
+
+def test_sampler_device_rng_properties():
+    from hpcs_amd.miner.loss_and_miner_utils import get_balanced_random_triplet_indices, TripletPlan
+    lab = det_int((4096,), 5, 7)
+    a, p, n = get_balanced_random_triplet_indices(lab.to(dev), t_per_anchor=50, fraction=1.2, rng="device", seed=3)
+    a, p, n = a.cpu(), p.cpu(), n.cpu()
+    plan = TripletPlan.from_labels(lab, 50, 1.2)
+    assert a.numel() == plan.T == sum(int(c) * int(k) for c, k in zip(plan.counts, plan.k))
+    assert bool((lab[a] == lab[p]).all()) and bool((a != p).all()) and bool((lab[a] != lab[n]).all())
+    # every anchor appears exactly k_l times; positives/negatives roughly uniform
+    cnt = torch.bincount(a, minlength=4096)
+    assert bool((cnt == plan.k[lab].long()).all())
+    neg_hist = torch.bincount(n, minlength=4096).float()
+    assert float(neg_hist.std() / neg_hist.mean()) < 0.2
+    a2, p2, n2 = get_balanced_random_triplet_indices(lab.to(dev), t_per_anchor=50, fraction=1.2, rng="device", seed=4)
+    assert not torch.equal(p2.cpu(), p)
+
+
+@pytest.mark.parametrize("kind,margin", [("easy", 0.0), ("semihard", 0.35), ("hard", 0.1), ("all", 0.2)])
+def test_miner_filter(kind, margin):
+    from hpcs_amd.miner.triplet_margin_miner import RandomTripletMarginMiner
+    M, E = 1500, 32
+    x = OH.expmap0(det_normalish((M, E), 7) * 0.6)
+    lab = det_int((M,), 8, 5)
+    torch.manual_seed(7)
+    wa, wp, wn = OM.mine_triplets(x, lab, 20, 1.2, margin, kind)
+    torch.manual_seed(7)
+    miner = RandomTripletMarginMiner(t_per_anchor=20, fraction=1.2, margin=margin, type_of_triplets=kind)
+    a, p, n = miner(x.to(dev), lab.to(dev))
+    got = torch.stack([a, p, n]).cpu()
+    want = torch.stack([wa, wp, wn])
+    if got.shape == want.shape and torch.equal(got, want):
+        return
+    # borderline margins may flip with the dot-product summation order: allow only such differences
+    mat = OM.cosine_sim_mat(x)
+    torch.manual_seed(7)
+    fa, fp_, fn = OM.balanced_triplets(lab, 20, 1.2)
+    tm = (mat[fa, fp_] - mat[fa, fn])
+    edge = (tm - margin).abs() < 1e-6
+    if kind in ("semihard", "hard"):
+        edge |= tm.abs() < 1e-6
+    key = lambda t: set(map(tuple, t.t().tolist()))
+    diff = key(got) ^ key(want)
+    border = key(torch.stack([fa[edge], fp_[edge], fn[edge]]))
+    assert diff <= border and len(diff) <= 8
+
+
+@pytest.mark.parametrize("s", [1e-3, 1e-2, 0.3, 0.9])   # at s=1 the reference's construction is NaN (points on the boundary)
+def test_hyphc_loss_and_grads(s):
+    from hpcs_amd.loss.ultrametric_loss import MetricHyperbolicLoss
+    M, E, C = 2000, 32, 6
+    x = OH.expmap0(det_normalish((M, E), 11) * 0.5)
+    lab = det_int((M,), 12, C)
+    scale = torch.nn.Parameter(torch.tensor([s]))
+    crit = MetricHyperbolicLoss(margin=0.35, t_per_anchor=10, fraction=1.2, scale=scale, temperature=0.05,
+                                num_class=C, embedding_size=E, cosface=True, miner=True).to(dev)
+    scale_d = crit.scale            # registered as a parameter of the loss module (as in the reference)
+    assert scale_d.is_cuda
+    W = det_normalish((E, C), 13)
+    crit.loss_cosface.W.data.copy_(W)
+    xg = x.to(dev).requires_grad_(True)
+    torch.manual_seed(5)
+    out = crit.compute_loss(None, xg, lab.to(dev))
+    lh, lm = out["loss_hyp"]["losses"], out["loss_metric"]["losses"]
+    a, p, n, count = crit.last_triplets
+    c = int(count)
+    trip = (a[:c].cpu(), p[:c].cpu(), n[:c].cpu())
+    # oracle on the SAME triplets, fp64 (ground truth) and fp32 reference-order
+    x64 = x.double().requires_grad_(True)
+    s64 = torch.tensor([s], dtype=torch.float64, requires_grad=True)
+    W64 = W.double().requires_grad_(True)
+    lh64 = OM.hyphc_loss(x64, trip, s64, 0.05, mat_mean="closed")
+    lm64 = OM.cosface_loss(x64, lab, W64, 0.35, 2.0)
+    lh32 = OM.hyphc_loss_gathered(x, trip, torch.tensor([s]), 0.05)
+    assert abs(float(lh) - float(lh64)) <= 2e-6 * abs(float(lh64))
+    assert abs(float(lm) - float(lm64)) <= 1e-5 * abs(float(lm64))
+    # against the fp32 reference formulation (materialised matrix, reflections): north-star 1e-5
+    assert abs(float(lh) - float(lh32)) <= 1e-5 * abs(float(lh32))
+    (0.1 * lh + lm).backward()
+    (0.1 * lh64 + lm64).backward()
+    relclose(xg.grad, x64.grad, 2e-4)
+    relclose(crit.loss_cosface.W.grad, W64.grad, 2e-4)
+    if s < 1.0:
+        assert abs(float(scale_d.grad) - float(s64.grad)) <= 1e-3 * abs(float(s64.grad)) + 1e-9
+    # mined triplets equal the oracle's miner under the same seed (up to borderline flips)
+    torch.manual_seed(5)
+    wa, wp, wn = OM.mine_triplets(x, lab, 10, 1.2, 0, "easy")
+    assert abs(wa.numel() - c) <= 8
+
+
+def test_triplet_branch_loss_and_grads():
+    from hpcs_amd.loss.ultrametric_loss import MetricHyperbolicLoss
+    M, E, C = 1200, 16, 4
+    x = OH.expmap0(det_normalish((M, E), 21) * 0.7)
+    lab = det_int((M,), 22, C)
+    scale = torch.tensor([0.05], device=dev, requires_grad=True)
+    crit = MetricHyperbolicLoss(margin=0.35, t_per_anchor=8, fraction=1.2, scale=scale, temperature=0.05, num_class=C,
+                                embedding_size=E, cosface=False, miner=True)
+    xg = x.to(dev).requires_grad_(True)
+    torch.manual_seed(9)
+    out = crit.compute_loss(None, xg, lab.to(dev))
+    lm = out["loss_metric"]["losses"]
+    torch.manual_seed(9)
+    OM.mine_triplets(x, lab, 8, 1.2, 0, "easy")               # consume the hyp miner's draws
+    t2 = OM.mine_triplets(x, lab, 8, 1.2, 0.35, "semihard")
+    x64 = x.double().requires_grad_(True)
+    want = OM.triplet_margin_loss(x64, t2, 0.35)
+    assert abs(float(lm) - float(want)) <= 1e-4 * abs(float(want))
+    lm.backward()
+    want.backward()
+    relclose(xg.grad, x64.grad, 2e-3)
+    assert not hasattr(crit, "loss_cosface")
+    with pytest.raises(ValueError):
+        crit.get_logits(xg, lab.to(dev))
+
+
+def test_get_logits_and_cosine_matrix():
+    from hpcs_amd.loss.ultrametric_loss import MetricHyperbolicLoss
+    from hpcs_amd.distances import CosineSimilarity
+    M, E, C = 300, 8, 5
+    x = det_normalish((M, E), 31) * 0.4
+    lab = det_int((M,), 32, C)
+    crit = MetricHyperbolicLoss(num_class=C, embedding_size=E, cosface=True, miner=True).to(dev)
+    W = crit.loss_cosface.W.detach().cpu()
+    close(crit.get_logits(x.to(dev), lab.to(dev)), OM.cosface_logits(x, lab, W, 0.35, 2.0), rtol=1e-5, atol=1e-6)
+    close(CosineSimilarity()(x.to(dev)), OM.cosine_sim_mat(x), rtol=1e-5, atol=1e-6)
+    close(crit.normalize_embeddings(x.to(dev)), OM.scale_to_diameter(x, torch.tensor([1e-3])), rtol=1e-5, atol=1e-9)
+
+
+def test_radam_matches_reference(golden):
+    from hpcs_amd.optim import RAdam
+    shapes = (((5, 7), 0.3), ((6,), 0.5), ((4, 3, 1), 0.8), ((1,), 1e-3), ((3, 4), 2.0))
+    ps = [torch.nn.Parameter((det_uniform(s, 120 + i) * sc).to(dev)) for i, (s, sc) in enumerate(shapes)]
+    opt = RAdam(ps, lr=0.05)
+    for step in range(3):
+        for i, p_ in enumerate(ps):
+            p_.grad = (det_uniform(tuple(p_.shape), 130 + 10 * step + i) * 0.7).to(dev)
+        opt.step()
+        for i, p_ in enumerate(ps):
+            close(p_, golden[f"radam_step{step}_p{i}"], rtol=2e-5, atol=1e-7)
+    for i, p_ in enumerate(ps):
+        close(opt.state[p_]["exp_avg"], golden[f"radam_final_m{i}"], rtol=2e-5, atol=1e-7)
+        close(opt.state[p_]["exp_avg_sq"], golden[f"radam_final_v{i}"], rtol=2e-5, atol=1e-9)
