@@ -101,8 +101,28 @@ def _dev_ptr(t):
     return t.data_ptr()
 
 
-def call(name, *args):
+# Optional per-entry-point timing with events on the launch stream (bench.py's roofline leg).
+# PROFILE = {"hpcs_knn": [(start_event, end_event, tag), ...], ...}; only names present as keys are timed.
+PROFILE = None
+
+
+def call(name, *args, tag=None):
     """Calls an entry point; tensors become device pointers, the stream argument is appended."""
+    if PROFILE is not None and name in PROFILE:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = _call(name, *args)
+        e1.record()
+        PROFILE[name].append((e0, e1, tag if tag is not None else _shape_tag(name, args)))
+        return rc
+    return _call(name, *args)
+
+
+def _shape_tag(name, args):
+    return tuple(a for a in args if isinstance(a, int) and not isinstance(a, bool))
+
+
+def _call(name, *args):
     kinds, ret = SIGNATURES[name]
     fn = _fn(name)
     conv = []

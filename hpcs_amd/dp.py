@@ -1,0 +1,74 @@
+"""Data parallelism for the HPCS step: one process per GPU, one gradient all-reduce per step over RCCL/xGMI.
+
+The reference has no distributed code at all (no strategy/devices on its Trainer); what its
+Lightning stack would do with devices>1 is DDP without SyncBN, which is what this reproduces: clouds are sharded
+across ranks, BatchNorm statistics and triplet mining stay per-replica, and only the 1.3 M-float gradient is
+exchanged.  All .grad tensors are views into ONE flat fp32 bucket, so the collective needs no pack/unpack:
+autograd accumulates straight into the bucket, the bucket is all-reduced in place and scaled by 1/world.
+"""
+import torch
+import torch.distributed as dist
+
+from . import _lib
+
+
+class FlatGradBucket:
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        dev = self.params[0].device
+        total = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            off += n
+        self.numel = total
+
+    def zero(self):
+        self.flat.zero_()
+        for p in self.params:          # re-attach in case something replaced .grad
+            if p.grad is None or p.grad.data_ptr() < self.flat.data_ptr() or \
+                    p.grad.data_ptr() >= self.flat.data_ptr() + 4 * self.numel:
+                raise RuntimeError("a parameter's .grad no longer aliases the flat bucket (use bucket.zero(), not "
+                                   "optimizer.zero_grad(set_to_none=True))")
+
+    def all_reduce_mean(self, group=None):
+        """Sum over ranks, then scale by 1/world (in place).  No-op when not distributed."""
+        if not (dist.is_available() and dist.is_initialized()):
+            return
+        world = dist.get_world_size(group)
+        if world == 1:
+            return
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+        if self.flat.is_cuda:
+            _lib.call("hpcs_scale_inplace", self.flat, self.numel, 1.0 / world)
+        else:                              # gloo / CPU rehearsal of the collective path (tests only)
+            self.flat.mul_(1.0 / world)
+
+
+def init_distributed(backend=None):
+    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun).  Returns (rank, local_rank, world)."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"     # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def broadcast_parameters(module, src=0):
+    """Make every replica start from rank `src`'s parameters and buffers."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src=src)

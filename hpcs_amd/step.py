@@ -1,0 +1,88 @@
+"""Training-step driver: the ordering of BaseSimilarityHypHC.forward / training_step + RAdam.step
+(hpcs/models/base_hyp_hc.py:101-171, hpcs/models/shapenet_hyp_hc.py:55-91) without Lightning.
+
+The reference's LightningModule is the CALLER of the hot path and stays out of scope; this
+module is the minimal stand-in that the benchmark, the smoke test and the data-parallel wrapper drive:
+
+    rotate (SO(3), on device) -> nn_feat -> nn_emb -> flatten -> MetricHyperbolicLoss.compute_loss
+    -> total = loss_metric + trade_off*loss_hyp -> backward -> [all-reduce] -> RAdam.step
+"""
+import torch
+
+from .dp import FlatGradBucket
+from .loss.ultrametric_loss import MetricHyperbolicLoss
+from .optim import RAdam
+
+
+def random_rotations(B, device, generator=None):
+    """Haar-uniform SO(3) matrices [B,3,3] from sign-fixed QR of Gaussian matrices (on device)."""
+    g = torch.randn(B, 3, 3, device=device, generator=generator)
+    q, r = torch.linalg.qr(g)
+    q = q * torch.sign(torch.diagonal(r, dim1=-2, dim2=-1)).unsqueeze(-2)
+    det = torch.linalg.det(q)
+    q[:, :, 0] = q[:, :, 0] * det.unsqueeze(-1)
+    return q
+
+
+def to_categorical(y, num_classes):
+    """1-hot encode (hpcs/utils/data.py:24-29), on the device of y."""
+    return torch.nn.functional.one_hot(y.long(), num_classes).float()
+
+
+class HypHCStep(torch.nn.Module):
+    def __init__(self, nn_feat, nn_emb, hyp_size, num_class, num_categories=16, lr=1e-3, margin=0.5, t_per_anchor=50,
+                 fraction=1.2, temperature=0.05, anneal_factor=0.5, trade_off=0.1, miner=True, cosface=True,
+                 train_rotation="so3", rng="device"):
+        super().__init__()
+        self.nn_feat = nn_feat
+        self.nn_emb = nn_emb
+        self.num_categories = num_categories
+        self.trade_off = trade_off
+        self.train_rotation = train_rotation
+        self.scale = torch.nn.Parameter(torch.Tensor([1e-3]), requires_grad=True)        # base_hyp_hc.py:62
+        self.metric_hyp_loss = MetricHyperbolicLoss(margin=margin, t_per_anchor=t_per_anchor, fraction=fraction,
+                                                    scale=self.scale, temperature=temperature,
+                                                    anneal_factor=anneal_factor, num_class=num_class,
+                                                    embedding_size=hyp_size, miner=miner, cosface=cosface, rng=rng)
+        self.lr = lr
+        self.optimizer = None
+        self.bucket = None
+
+    def configure(self):
+        """Call once the module is on its device: flat gradient bucket + RAdam over ALL parameters (base_hyp_hc.py:143)."""
+        params = list(self.parameters())
+        self.bucket = FlatGradBucket(params)
+        self.optimizer = RAdam(params, lr=self.lr)
+        return self
+
+    def forward_losses(self, points, label, targets, plan=None, rot=None, drop_masks=None):
+        """points [B,N,3], label [B] category ids, targets [B,N] part ids (all on the device)."""
+        B = points.shape[0]
+        if self.train_rotation == "so3":
+            R = random_rotations(B, points.device) if rot is None else rot
+            points = torch.matmul(points, R)              # transform_points: row vectors times R
+        x = points.transpose(2, 1).contiguous().float()
+        decode = to_categorical(label, self.num_categories)
+        x_euclidean = self.nn_feat(x, decode) if drop_masks is None else self.nn_feat(x, decode, drop_masks=drop_masks)
+        x_poincare = self.nn_emb(x_euclidean) if self.nn_emb is not None else x_euclidean
+        xe = x_euclidean.contiguous().view(-1, x_euclidean.shape[-1])
+        xp = x_poincare.contiguous().view(-1, x_poincare.shape[-1])
+        y = targets.reshape(-1).long()
+        loss = self.metric_hyp_loss.compute_loss(xe, xp, y, plan=plan)
+        return {"loss_metric": loss["loss_metric"]["losses"],
+                "loss_hyp": loss["loss_hyp"]["losses"] * self.trade_off}
+
+    def training_step(self, points, label, targets, targets_host=None, rot=None, drop_masks=None):
+        """One optimisation step.  targets_host (CPU copy of the part labels) lets the miner's per-class plan be
+        computed without a device->host sync in the middle of the step."""
+        plan = None
+        if targets_host is not None and self.metric_hyp_loss.miner:
+            plan = self.metric_hyp_loss.make_plan(targets_host)
+        self.bucket.zero()
+        losses = self.forward_losses(points, label, targets, plan=plan, rot=rot, drop_masks=drop_masks)
+        total = losses["loss_metric"] + losses["loss_hyp"]
+        total.backward()
+        self.bucket.all_reduce_mean()
+        self.optimizer.step()
+        losses["total_loss"] = total.detach()
+        return losses
