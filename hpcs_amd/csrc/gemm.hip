@@ -225,15 +225,27 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(
         }
 }
 
-__global__ void split_reduce_kernel(const float* __restrict__ part, int nsplit, int M, int Kx, float* __restrict__ dW,
-                                    int lddw, int accumulate) {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= (int64_t)M * Kx) return;
+// Sums the split partials in a FIXED order (deterministic).  64 outputs per workgroup, 16 waves each own every
+// 16th split, the 16 partial sums are then added in wave order.
+__global__ __launch_bounds__(1024) void split_reduce_kernel(const float* __restrict__ part, int nsplit, int M, int Kx,
+                                                            float* __restrict__ dW, int lddw, int accumulate) {
+    __shared__ float sh[16][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t e = (int64_t)blockIdx.x * 64 + lane;
+    const int64_t ne = (int64_t)M * Kx;
     float s = 0.f;
-    for (int i = 0; i < nsplit; ++i) s += part[(int64_t)i * M * Kx + e];   // fixed order: deterministic
-    const int row = (int)(e / Kx), col = (int)(e % Kx);
-    float* d = dW + (int64_t)row * lddw + col;
-    *d = accumulate ? *d + s : s;
+    if (e < ne)
+        for (int i = w; i < nsplit; i += 16) s += part[(int64_t)i * ne + e];
+    sh[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && e < ne) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += sh[i][lane];
+        const int row = (int)(e / Kx), col = (int)(e % Kx);
+        float* d = dW + (int64_t)row * lddw + col;
+        *d = accumulate ? *d + t : t;
+    }
 }
 
 constexpr int NT_BM = 64, NT_BN = 64, NT_BKC = 32;
@@ -313,7 +325,7 @@ extern "C" int hpcs_gemm_nt(const float* G, int ldg, int64_t strideG_o, int64_t 
                        p.units_per_batch, p.nsplit, (float*)ws, p.tilesM, p.tilesK, vecG, vecX);
     HPCS_CHECK_LAUNCH();
     const int64_t ne = (int64_t)M * Kx;
-    hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)hpcs_cdiv(ne, 256)), dim3(256), 0, st, (const float*)ws,
+    hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)hpcs_cdiv(ne, 64)), dim3(1024), 0, st, (const float*)ws,
                        p.nsplit, M, Kx, dW, lddw, accumulate);
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;

@@ -154,11 +154,32 @@ __global__ void filter_flag_kernel(const float* __restrict__ xn, int E, const in
 
 __global__ void filter_scan_kernel(const int32_t* __restrict__ block_cnt, int nblocks, int64_t* __restrict__ block_off,
                                    int64_t* __restrict__ count) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        int64_t acc = 0;
-        for (int i = 0; i < nblocks; ++i) { block_off[i] = acc; acc += block_cnt[i]; }
-        *count = acc;
+    // one workgroup: each thread owns a contiguous segment, workgroup-wide exclusive scan of the segment sums
+    __shared__ int64_t wsum[TPB / 64];
+    const int per = (nblocks + TPB - 1) / TPB;
+    const int b0 = threadIdx.x * per, b1 = min(nblocks, b0 + per);
+    int64_t mine = 0;
+    for (int i = b0; i < b1; ++i) mine += block_cnt[i];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int64_t incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int64_t v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
     }
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    int64_t before = 0, total = 0;
+    for (int j = 0; j < TPB / 64; ++j) {
+        if (j < w) before += wsum[j];
+        total += wsum[j];
+    }
+    int64_t run = before + incl - mine;
+    for (int i = b0; i < b1; ++i) {
+        block_off[i] = run;
+        run += block_cnt[i];
+    }
+    if (threadIdx.x == 0) *count = total;
 }
 
 __global__ void filter_scatter_kernel(const uint8_t* __restrict__ flags, const int64_t* __restrict__ block_off,
@@ -197,110 +218,194 @@ __global__ void filter_scatter_kernel(const uint8_t* __restrict__ flags, const i
 }
 
 // ---------------------------------------------------------------------------------------------- HypHC
-struct LcaW { double d, dd_dw, dd_ds; };
+// d(s, dot) = 2 artanh(m), m = 1/(C + sqrt(C^2-1)), C = (1+s^2)/(2 s sqrt(w)), w = (1+dot)/2, and its partials.
+// fp32 with cancellation-free forms: C-1 = ((1-s)^2 + 2 s (1-w)/(1+sqrt w)) / (2 s sqrt w), C^2-1 = (C-1)(C+1).
+struct LcaF { float d, dd_dw, dd_ds; };
 
-// d(s, w) and its partials; w = 0.5*(1+cos) in [0,1], s in [1e-4,1]
-__device__ __forceinline__ LcaW lca_of_sim(double s, double w) {
-    LcaW r;
-    const double wc = fmax(w, 1e-12);
-    const double sq = sqrt(wc);
-    const double C = fmax((1.0 + s * s) / (2.0 * s * sq), 1.0);
-    const double root = sqrt(fmax(C * C - 1.0, 0.0));
-    const double m = 1.0 / (C + root);
-    float mf = (float)m;                                      // Artanh clamps the fp32 value
-    mf = fminf(mf, 1.f - 1e-5f);
-    const double mc = (double)mf;
-    r.d = log1p(mc) - log1p(-mc);                             // 2*artanh
-    const double dd_dm = 2.0 / (1.0 - mc * mc);
-    const double dm_dC = -m / fmax(root, 1e-12);
-    const double g = dd_dm * dm_dC;
-    r.dd_dw = g * (-C / (2.0 * wc));
-    r.dd_ds = g * (C * (s * s - 1.0) / (s * (1.0 + s * s)));
+__device__ __forceinline__ LcaF lca_of_dot(float s, float dot) {
+    LcaF r;
+    const float w = fmaxf(0.5f * (1.f + dot), 1e-12f);
+    const float omw = fmaxf(0.5f * (1.f - dot), 0.f);
+    const float sq = sqrtf(w);
+    const float den = 2.f * s * sq;
+    const float Cm1 = ((1.f - s) * (1.f - s) + 2.f * s * omw / (1.f + sq)) / den;
+    const float C = 1.f + Cm1;
+    const float root = sqrtf(Cm1 * (C + 1.f));
+    const float m = 1.f / (C + root);
+    const float mc = fminf(m, 1.f - 1e-5f);                   // Artanh's input clamp
+    r.d = log1pf(mc) - log1pf(-mc);                           // 2*artanh
+    const float g = (2.f / (1.f - mc * mc)) * (-m / fmaxf(root, 1e-20f));
+    r.dd_dw = g * (-C / (2.f * w));
+    r.dd_ds = g * (C * (s * s - 1.f) / (s * (1.f + s * s)));
     return r;
 }
 
-__device__ __forceinline__ void triplet_sims(const float* __restrict__ xn, int E, int64_t ia, int64_t ip, int64_t in, int s,
-                                             float& wij, float& wik, float& wjk) {
-    float d1 = 0.f, d2 = 0.f, d3 = 0.f;
-    for (int e = s; e < E; e += SUB) {
-        const float av = xn[ia * E + e], pv = xn[ip * E + e], nv = xn[in * E + e];
-        d1 += av * pv;
-        d2 += av * nv;
-        d3 += pv * nv;
-    }
-    wij = 0.5f * (1.f + sub_sum(d1));
-    wik = 0.5f * (1.f + sub_sum(d2));
-    wjk = 0.5f * (1.f + sub_sum(d3));
-}
+constexpr int RUN = 16;          // consecutive triplets walked by one 8-lane group (they mostly share the anchor)
 
-__global__ void hyphc_fwd_kernel(const float* __restrict__ xn, int E, const int64_t* __restrict__ a, const int64_t* __restrict__ p,
-                                 const int64_t* __restrict__ n, const int64_t* __restrict__ count, int64_t T_cap,
-                                 const float* __restrict__ scale, float temperature, double* __restrict__ loss_sum) {
-    __shared__ double red[16];
-    const int64_t T = *count < T_cap ? *count : T_cap;
-    const double sc = (double)fminf(fmaxf(*scale, 1e-4f), 1.f);
-    const int s = threadIdx.x % SUB, g = threadIdx.x / SUB;
-    double acc = 0.0;
-    for (int64_t t = (int64_t)blockIdx.x * TRIP_PER_PASS + g; t - g < T; t += (int64_t)gridDim.x * TRIP_PER_PASS) {
-        const bool live = t < T;
-        const int64_t ia = live ? a[t] : 0, ip = live ? p[t] : 0, in = live ? n[t] : 0;
-        float w[3];
-        triplet_sims(xn, E, ia, ip, in, s, w[0], w[1], w[2]);
-        if (live && s == 0) {
-            double d[3], mx = -1e300;
-            for (int i = 0; i < 3; ++i) { d[i] = lca_of_sim(sc, (double)w[i]).d / (double)temperature; mx = fmax(mx, d[i]); }
-            double den = 0.0, num = 0.0, sw = 0.0;
-            for (int i = 0; i < 3; ++i) { const double ex = exp(d[i] - mx); den += ex; num += ex * (double)w[i]; sw += (double)w[i]; }
-            acc += sw - num / den;
-        }
-    }
-    const double tot = hpcs_block_sum<double>(acc, red);
-    if (threadIdx.x == 0 && tot != 0.0) atomicAdd(loss_sum, tot);
-}
+// EPL = ceil(E/8) elements per lane, rows live in registers.
+__device__ __forceinline__ int sub_lane0(int lane) { return lane & ~(SUB - 1); }
 
-__global__ void hyphc_bwd_kernel(const float* __restrict__ xn, int E, const int64_t* __restrict__ a, const int64_t* __restrict__ p,
-                                 const int64_t* __restrict__ n, const int64_t* __restrict__ count, int64_t T_cap,
-                                 const float* __restrict__ scale, float temperature, const float* __restrict__ gloss,
-                                 float* __restrict__ gxn, double* __restrict__ gscale) {
+// FAST: E == 8*EPL exactly (E = 16, 32, 64): row-contiguous atomics via an LDS transpose.
+template <int EPL, bool BWD, bool FAST>
+__global__ __launch_bounds__(TPB) void hyphc_kernel(const float* __restrict__ xn, int E, const int64_t* __restrict__ a,
+                                                    const int64_t* __restrict__ p, const int64_t* __restrict__ n,
+                                                    const int64_t* __restrict__ count, int64_t T_cap,
+                                                    const float* __restrict__ scale, float temperature,
+                                                    const float* __restrict__ gloss, double* __restrict__ loss_sum,
+                                                    float* __restrict__ gxn, double* __restrict__ gscale, unsigned perm_mul) {
     __shared__ double red[16];
+    __shared__ float stage[(BWD && FAST) ? (TPB / 64) * 2 * 8 * (8 * EPL + 8) : 1];
     const int64_t T = *count < T_cap ? *count : T_cap;
     const float sraw = *scale;
-    const double sc = (double)fminf(fmaxf(sraw, 1e-4f), 1.f);
-    const bool s_live = sraw >= 1e-4f && sraw <= 1.f;          // torch.clamp passes the gradient inside the range
-    const double up = T > 0 ? (double)(*gloss) / (double)T : 0.0;
+    const float sc = fminf(fmaxf(sraw, 1e-4f), 1.f);
+    const bool s_live = sraw >= 1e-4f && sraw <= 1.f;         // torch.clamp passes the gradient inside the range only
+    const float inv_t = 1.f / temperature;
+    float up = 0.f;
+    if (BWD) up = T > 0 ? (float)((double)(*gloss) / (double)T) : 0.f;
+    const int lane = threadIdx.x & 63;
     const int s = threadIdx.x % SUB, g = threadIdx.x / SUB;
-    double gs_acc = 0.0;
-    for (int64_t t = (int64_t)blockIdx.x * TRIP_PER_PASS + g; t - g < T; t += (int64_t)gridDim.x * TRIP_PER_PASS) {
+    const int sub0 = lane & ~(SUB - 1);
+    // Triplets are ordered by class; co-resident workgroups would all add into the same few hundred positive rows.
+    // A multiplicative permutation of the block id spreads concurrent workgroups over the whole triplet list.
+    const unsigned pblock = (unsigned)(((uint64_t)blockIdx.x * perm_mul) % gridDim.x);
+    const int64_t base = ((int64_t)pblock * TRIP_PER_PASS + g) * RUN;
+
+    double acc = 0.0;
+    float acc_a[EPL];
+    int64_t cur = -1;
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) acc_a[j] = 0.f;
+
+    for (int i = 0; i < RUN; ++i) {
+        const int64_t t = base + i;
         const bool live = t < T;
         const int64_t ia = live ? a[t] : 0, ip = live ? p[t] : 0, in = live ? n[t] : 0;
-        float w[3];
-        triplet_sims(xn, E, ia, ip, in, s, w[0], w[1], w[2]);
-        float gw[3] = {0.f, 0.f, 0.f};
-        if (live) {          // every lane of the sub-group evaluates the scalars (cheaper than a broadcast)
-            LcaW L[3];
-            double d[3], mx = -1e300;
-            for (int i = 0; i < 3; ++i) { L[i] = lca_of_sim(sc, (double)w[i]); d[i] = L[i].d / (double)temperature; mx = fmax(mx, d[i]); }
-            double ex[3], den = 0.0, num = 0.0;
-            for (int i = 0; i < 3; ++i) { ex[i] = exp(d[i] - mx); den += ex[i]; num += ex[i] * (double)w[i]; }
-            const double wbar = num / den;
-            for (int i = 0; i < 3; ++i) {
-                const double sm = ex[i] / den;
-                const double gd = -(sm * ((double)w[i] - wbar)) / (double)temperature;   // d loss_t / d d_i
-                gw[i] = (float)(up * ((1.0 - sm) + gd * L[i].dd_dw));
-                if (s == 0 && s_live) gs_acc += up * gd * L[i].dd_ds;
+        float av[EPL], pv[EPL], nv[EPL];
+        float d1 = 0.f, d2 = 0.f, d3 = 0.f;
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+            const int e = s + SUB * j;
+            const bool ok = e < E;
+            av[j] = ok ? xn[ia * E + e] : 0.f;
+            pv[j] = ok ? xn[ip * E + e] : 0.f;
+            nv[j] = ok ? xn[in * E + e] : 0.f;
+            d1 += av[j] * pv[j];
+            d2 += av[j] * nv[j];
+            d3 += pv[j] * nv[j];
+        }
+        d1 = sub_sum(d1);
+        d2 = sub_sum(d2);
+        d3 = sub_sum(d3);
+        // lane s (<3) of the group evaluates similarity s; lanes >= 3 shadow similarity 2
+        const float my_dot = s == 0 ? d1 : (s == 1 ? d2 : d3);
+        const LcaF L = lca_of_dot(sc, my_dot);
+        const float dsc = L.d * inv_t;
+        const float q0 = __shfl(dsc, sub0, 64), q1 = __shfl(dsc, sub0 + 1, 64), q2 = __shfl(dsc, sub0 + 2, 64);
+        const float mx = fmaxf(q0, fmaxf(q1, q2));
+        const float ex = __expf(dsc - mx);
+        const float e0 = __shfl(ex, sub0, 64), e1 = __shfl(ex, sub0 + 1, 64), e2 = __shfl(ex, sub0 + 2, 64);
+        const float w0 = 0.5f * (1.f + d1), w1 = 0.5f * (1.f + d2), w2 = 0.5f * (1.f + d3);
+        const float den = e0 + e1 + e2;
+        const float wbar = (e0 * w0 + e1 * w1 + e2 * w2) / den;
+        if (!BWD) {
+            if (live && s == 0) acc += (double)((w0 + w1 + w2) - wbar);
+        } else {
+            const float my_w = s == 0 ? w0 : (s == 1 ? w1 : w2);
+            const float sm = ex / den;
+            const float gd = -(sm * (my_w - wbar)) * inv_t;                    // d loss_t / d d_s
+            const float gw = up * ((1.f - sm) + gd * L.dd_dw);
+            if (live && s < 3 && s_live) acc += (double)(up * gd * L.dd_ds);
+            const float c0 = 0.5f * __shfl(gw, sub0, 64), c1 = 0.5f * __shfl(gw, sub0 + 1, 64),
+                        c2 = 0.5f * __shfl(gw, sub0 + 2, 64);
+            if (live) {
+                if (ia != cur) {                       // anchor changed: flush the register accumulator
+                    if (cur >= 0) {
+#pragma unroll
+                        for (int j = 0; j < EPL; ++j)
+                            if (s + SUB * j < E) atomicAdd(gxn + cur * E + s + SUB * j, acc_a[j]);
+                    }
+                    cur = ia;
+#pragma unroll
+                    for (int j = 0; j < EPL; ++j) acc_a[j] = 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < EPL; ++j)
+                    if (s + SUB * j < E) acc_a[j] += c0 * pv[j] + c1 * nv[j];
             }
-            // w = 0.5*(1+dot): d/d xn rows
-            const float c0 = 0.5f * gw[0], c1 = 0.5f * gw[1], c2 = 0.5f * gw[2];
-            for (int e = s; e < E; e += SUB) {
-                const float av = xn[ia * E + e], pv = xn[ip * E + e], nv = xn[in * E + e];
-                atomicAdd(gxn + ia * E + e, c0 * pv + c1 * nv);
-                atomicAdd(gxn + ip * E + e, c0 * av + c2 * nv);
-                atomicAdd(gxn + in * E + e, c1 * av + c2 * pv);
+            if (FAST) {
+                // positive / negative rows are random: give every atomic wave-instruction whole contiguous rows
+                // (64/E rows x E floats = 256 B) by transposing the 8 triplets' updates through a wave-private LDS
+                // slab -- the full-rate shape of MI355X_MICROARCH "Global float atomics".
+                float* slab = stage + (threadIdx.x >> 6) * (2 * 8 * (8 * EPL + 8));
+                constexpr int LD = 8 * EPL + 8;
+                const int gi = (lane >> 3);
+#pragma unroll
+                for (int j = 0; j < EPL; ++j) {
+                    slab[gi * LD + s + SUB * j] = live ? c0 * av[j] + c2 * nv[j] : 0.f;
+                    slab[8 * LD + gi * LD + s + SUB * j] = live ? c1 * av[j] + c2 * pv[j] : 0.f;
+                }
+                __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): the slab is wave-private, no barrier needed
+                constexpr int RPI = 64 / (8 * EPL);          // rows per instruction
+#pragma unroll
+                for (int i = 0; i < EPL; ++i) {
+                    const int tl = i * RPI + lane / (8 * EPL), e = lane % (8 * EPL);
+                    const int64_t rp = __shfl(ip, tl * SUB, 64);
+                    const int64_t rn = __shfl(in, tl * SUB, 64);
+                    const bool lv = __shfl((int)live, tl * SUB, 64) != 0;
+                    if (lv) {
+                        atomicAdd(gxn + rp * E + e, slab[tl * LD + e]);
+                        atomicAdd(gxn + rn * E + e, slab[8 * LD + tl * LD + e]);
+                    }
+                }
+            } else if (live) {
+#pragma unroll
+                for (int j = 0; j < EPL; ++j) {
+                    const int e = s + SUB * j;
+                    if (e < E) {
+                        atomicAdd(gxn + ip * E + e, c0 * av[j] + c2 * nv[j]);
+                        atomicAdd(gxn + in * E + e, c1 * av[j] + c2 * pv[j]);
+                    }
+                }
             }
         }
     }
-    const double tot = hpcs_block_sum<double>(gs_acc, red);
-    if (threadIdx.x == 0 && tot != 0.0) atomicAdd(gscale, tot);
+    if (BWD && cur >= 0) {
+#pragma unroll
+        for (int j = 0; j < EPL; ++j)
+            if (s + SUB * j < E) atomicAdd(gxn + cur * E + s + SUB * j, acc_a[j]);
+    }
+    const double tot = hpcs_block_sum<double>(acc, red);
+    if (threadIdx.x == 0 && tot != 0.0) atomicAdd(BWD ? gscale : loss_sum, tot);
+}
+
+template <bool BWD>
+int launch_hyphc(const float* xn, int E, const int64_t* a, const int64_t* p, const int64_t* n, const int64_t* count,
+                 int64_t T_cap, const float* scale, float temperature, const float* gloss, double* loss_sum, float* gxn,
+                 double* gscale, hipStream_t st) {
+    const int64_t per_block = (int64_t)TRIP_PER_PASS * RUN;
+    const dim3 grid((unsigned)((T_cap + per_block - 1) / per_block));
+    unsigned perm_mul = 1;
+    if (BWD) {
+        static const unsigned primes[] = {7919u, 7907u, 7901u, 7883u, 7879u, 7877u};
+        for (unsigned pm : primes)
+            if (grid.x % pm != 0) { perm_mul = pm; break; }
+    }
+#define HPCS_HYPHC_CASE(EPL)                                                                                          \
+    if (E <= 8 * EPL) {                                                                                               \
+        if (BWD && E == 8 * EPL && EPL >= 2)                                                                          \
+            hipLaunchKernelGGL((hyphc_kernel<EPL, BWD, true>), grid, dim3(TPB), 0, st, xn, E, a, p, n, count, T_cap, \
+                               scale, temperature, gloss, loss_sum, gxn, gscale, perm_mul);                           \
+        else                                                                                                          \
+            hipLaunchKernelGGL((hyphc_kernel<EPL, BWD, false>), grid, dim3(TPB), 0, st, xn, E, a, p, n, count, T_cap,\
+                               scale, temperature, gloss, loss_sum, gxn, gscale, perm_mul);                           \
+        return HPCS_OK;                                                                                               \
+    }
+    HPCS_HYPHC_CASE(1)
+    HPCS_HYPHC_CASE(2)
+    HPCS_HYPHC_CASE(4)
+    HPCS_HYPHC_CASE(8)
+#undef HPCS_HYPHC_CASE
+    return HPCS_ERR_UNSUPPORTED;       // embedding sizes above 64 (the reference uses 4..50)
 }
 
 // ---------------------------------------------------------------------------------------------- CosFace
@@ -359,25 +464,44 @@ __global__ void cosface_bwd_x_kernel(const float* __restrict__ wn, const int64_t
     }
 }
 
-// grad wrt wn [C,E]; one workgroup per class, threads over rows
+// grad wrt wn [C,E]: each workgroup takes a slab of rows, stages d(logit) [rows][C] in LDS, then thread o=(c,e)
+// reduces the slab and issues ONE atomic per output.
 __global__ void cosface_bwd_w_kernel(const float* __restrict__ xn, const int64_t* __restrict__ labels,
                                      const float* __restrict__ logits, const float* __restrict__ loss_rows, int M, int E,
-                                     int C, float scale, const float* __restrict__ gloss, float* __restrict__ gwn) {
-    __shared__ float red[16];
+                                     int C, float scale, const float* __restrict__ gloss, int rows_per_block,
+                                     float* __restrict__ gwn) {
+    extern __shared__ float dl[];        // [rows_per_block][C]
     const float gmean = *gloss / (float)M;
-    const int c = blockIdx.x;
-    for (int e = 0; e < E; ++e) {
-        float acc = 0.f;
-        for (int row = threadIdx.x; row < M; row += blockDim.x) {
-            const int lab = (int)labels[row];
-            const float* lr = logits + (int64_t)row * C;
-            const float lse = loss_rows[row] + lr[lab];
-            const float dl = (expf(lr[c] - lse) - (c == lab ? 1.f : 0.f)) * gmean * scale;
-            acc = __builtin_fmaf(dl, xn[(int64_t)row * E + e], acc);
-        }
-        const float tot = hpcs_block_sum<float>(acc, red);
-        if (threadIdx.x == 0) gwn[(int64_t)c * E + e] = tot;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int nr = min(rows_per_block, M - r0);
+    for (int i = threadIdx.x; i < nr * C; i += blockDim.x) {
+        const int row = r0 + i / C, c = i % C;
+        const int lab = (int)labels[row];
+        const float* lr = logits + (int64_t)row * C;
+        const float lse = loss_rows[row] + lr[lab];
+        dl[i] = (__expf(lr[c] - lse) - (c == lab ? 1.f : 0.f)) * gmean * scale;
     }
+    __syncthreads();
+    for (int o = threadIdx.x; o < C * E; o += blockDim.x) {
+        const int c = o / E, e = o % E;
+        float acc = 0.f;
+        for (int r = 0; r < nr; ++r) acc = __builtin_fmaf(dl[r * C + c], xn[(int64_t)(r0 + r) * E + e], acc);
+        atomicAdd(gwn + o, acc);
+    }
+}
+
+__device__ __forceinline__ void triplet_sims(const float* __restrict__ xn, int E, int64_t ia, int64_t ip, int64_t in, int s,
+                                             float& wij, float& wik, float& wjk) {
+    float d1 = 0.f, d2 = 0.f, d3 = 0.f;
+    for (int e = s; e < E; e += SUB) {
+        const float av = xn[ia * E + e], pv = xn[ip * E + e], nv = xn[in * E + e];
+        d1 += av * pv;
+        d2 += av * nv;
+        d3 += pv * nv;
+    }
+    wij = 0.5f * (1.f + sub_sum(d1));
+    wik = 0.5f * (1.f + sub_sum(d2));
+    wjk = 0.5f * (1.f + sub_sum(d3));
 }
 
 // ---------------------------------------------------------------------------------------------- triplet margin
@@ -496,7 +620,7 @@ extern "C" int hpcs_triplet_filter(const float* xn, int E, const int64_t* a, con
     hipLaunchKernelGGL(filter_flag_kernel, dim3((unsigned)nb), dim3(TPB), 0, ST, xn, E, a, p, n, T, margin, kind, flags,
                        block_cnt);
     HPCS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(filter_scan_kernel, dim3(1), dim3(64), 0, ST, block_cnt, (int)nb, block_off, count);
+    hipLaunchKernelGGL(filter_scan_kernel, dim3(1), dim3(TPB), 0, ST, block_cnt, (int)nb, block_off, count);
     HPCS_CHECK_LAUNCH();
     hipLaunchKernelGGL(filter_scatter_kernel, dim3((unsigned)nb), dim3(TPB), 0, ST, flags, block_off, a, p, n, T, a_out, p_out,
                        n_out);
@@ -511,8 +635,8 @@ extern "C" int hpcs_hyphc_fwd(const float* xn, int E, const int64_t* a, const in
     if (E <= 0 || T_cap < 0 || !(temperature > 0.f)) return HPCS_ERR_SHAPE;
     if (hipMemsetAsync(loss_sum, 0, sizeof(double), ST) != hipSuccess) return HPCS_ERR_HIP;
     if (T_cap == 0) return HPCS_OK;
-    hipLaunchKernelGGL(hyphc_fwd_kernel, dim3(trip_grid(T_cap)), dim3(TPB), 0, ST, xn, E, a, p, n, count, T_cap, scale,
-                       temperature, loss_sum);
+    const int rc = launch_hyphc<false>(xn, E, a, p, n, count, T_cap, scale, temperature, nullptr, loss_sum, nullptr, nullptr, ST);
+    if (rc) return rc;
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;
 }
@@ -524,8 +648,8 @@ extern "C" int hpcs_hyphc_bwd(const float* xn, int E, const int64_t* a, const in
     if (E <= 0 || T_cap < 0 || !(temperature > 0.f)) return HPCS_ERR_SHAPE;
     if (hipMemsetAsync(gscale, 0, sizeof(double), ST) != hipSuccess) return HPCS_ERR_HIP;
     if (T_cap == 0) return HPCS_OK;
-    hipLaunchKernelGGL(hyphc_bwd_kernel, dim3(trip_grid(T_cap)), dim3(TPB), 0, ST, xn, E, a, p, n, count, T_cap, scale,
-                       temperature, gloss, gxn, gscale);
+    const int rc = launch_hyphc<true>(xn, E, a, p, n, count, T_cap, scale, temperature, gloss, nullptr, gxn, gscale, ST);
+    if (rc) return rc;
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;
 }
@@ -553,8 +677,12 @@ extern "C" int hpcs_cosface_bwd(const float* xn, const float* wn, const int64_t*
     hipLaunchKernelGGL(cosface_bwd_x_kernel, dim3(hpcs_cdiv(M, 64)), dim3(64), (size_t)C * E * 4, ST, wn, labels, logits, M, E,
                        C, scale, gloss, gxn);
     HPCS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(cosface_bwd_w_kernel, dim3(C), dim3(TPB), 0, ST, xn, labels, logits, loss_rows, M, E, C, scale,
-                       gloss, gwn);
+    if (hipMemsetAsync(gwn, 0, sizeof(float) * C * E, ST) != hipSuccess) return HPCS_ERR_HIP;
+    int rpb = (48 * 1024) / (4 * C);
+    if (rpb > 256) rpb = 256;
+    if (rpb < 1) return HPCS_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(cosface_bwd_w_kernel, dim3(hpcs_cdiv(M, rpb)), dim3(TPB), (size_t)rpb * C * 4, ST, xn, labels, logits,
+                       loss_rows, M, E, C, scale, gloss, rpb, gwn);
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;
 }

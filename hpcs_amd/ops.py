@@ -108,7 +108,9 @@ class EdgeGatherFn(torch.autograd.Function):
         (idx,) = ctx.saved_tensors
         B, C, N, k = ctx.dims
         gx = torch.empty(B, C, 3, N, device=g.device, dtype=torch.float32)
-        call("hpcs_edge_gather_bwd", _f32c(g), idx, B, C, N, k, gx)
+        nbytes = call("hpcs_edge_gather_bwd_workspace", B, C, N)
+        ws = torch.empty(nbytes // 4, device=g.device, dtype=torch.float32)
+        call("hpcs_edge_gather_bwd", _f32c(g), idx, B, C, N, k, gx, ws, nbytes)
         return gx, None
 
 

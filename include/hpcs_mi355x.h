@@ -44,11 +44,13 @@ int hpcs_knn(const float* x, int B, int D, int N, int k, int64_t* idx, hpcs_stre
 
 /* ---- a2: get_graph_feature  hpcs/nn/dgcnn/utils/vn_dgcnn_util.py:13-41 ----------------------
  * x [B,C,3,N], idx [B,N,k] (cloud-local) -> out [B,2C,3,N,k] = (x[nbr]-x[ctr], x[ctr]).
- * bwd: gx [B,C,3,N] is overwritten (scatter-add over neighbours uses fp32 atomics). */
+ * bwd: gx [B,C,3,N] is overwritten; the neighbour scatter-add goes through a point-major scratch
+ * (hpcs_edge_gather_bwd_workspace bytes) with row-contiguous fp32 atomics. */
 int hpcs_edge_gather_fwd(const float* x, const int64_t* idx, int B, int C, int N, int k, float* out,
                          hpcs_stream_t stream);
-int hpcs_edge_gather_bwd(const float* gout, const int64_t* idx, int B, int C, int N, int k, float* gx,
-                         hpcs_stream_t stream);
+size_t hpcs_edge_gather_bwd_workspace(int B, int C, int N);
+int hpcs_edge_gather_bwd(const float* gout, const int64_t* idx, int B, int C, int N, int k, float* gx, void* ws,
+                         size_t ws_bytes, hpcs_stream_t stream);
 
 /* ---- channel mixing (nn.Linear over the channel axis / Conv1d k=1) -----------------------------
  * replaces map_to_feat / map_to_dir of vn_layers.py:14-24,48-77 and the Conv1d's of

@@ -1,0 +1,86 @@
+"""CPU-only: the C-ABI library loads and exports every declared symbol; the product never touches the oracle."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as g
+    g.build()
+    from hpcs_amd import _lib
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    names = _lib.exported_symbols_declared_in_header()
+    assert len(names) >= 50
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+    assert _lib.call("hpcs_version") >= 100
+
+
+def test_argument_validation_without_gpu():
+    """Entry points reject bad arguments before any HIP call (safe on a CPU-only box)."""
+    from hpcs_amd import _lib
+    L = _lib.lib()
+    f = L.hpcs_knn
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    assert f(None, 1, 3, 8, 2, None, None) == -4            # HPCS_ERR_NULL
+    assert f(1, 1, 3, 8, 9, 1, None) == -1                   # k > N: HPCS_ERR_SHAPE
+    assert f(1, 1, 3, 128, 65, 1, None) == -2                # k > 64: HPCS_ERR_UNSUPPORTED
+    g = L.hpcs_gemm_nt_workspace
+    g.restype = ctypes.c_size_t
+    g.argtypes = [ctypes.c_int] * 5
+    assert g(42, 42, 61440, 32, 1) > 0 and g(0, 1, 1, 1, 1) == 0
+
+
+def test_product_fails_loudly_on_cpu_tensors():
+    from hpcs_amd import _lib, ops
+    from hpcs_amd.nn.dgcnn import VN_DGCNN_partseg
+    from hpcs_amd.nn.hyperbolic import ExpMap
+    with pytest.raises(_lib.HpcsNativeError):
+        ops.knn(torch.zeros(1, 3, 16), 4)
+    net = VN_DGCNN_partseg(3, 4, k=4, dropout=0.0, pooling="mean", num_categories=2)
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(1, 3, 16), torch.zeros(1, 2))
+    with pytest.raises(_lib.HpcsNativeError):
+        ExpMap()(torch.zeros(2, 4))
+
+
+def test_state_dict_keys_match_reference_layout():
+    from hpcs_amd.nn.dgcnn import VN_DGCNN_partseg
+    from oracle.extractor import param_shapes
+    for pooling in ("mean", "max"):
+        net = VN_DGCNN_partseg(3, 32, k=20, dropout=0.5, pooling=pooling, num_categories=16)
+        sd = net.state_dict()
+        want = param_shapes(32, 16, pooling)
+        assert set(sd) == set(want)
+        for k_, shp in want.items():
+            assert tuple(sd[k_].shape) == tuple(shp), k_
+    assert sum(p.numel() for p in net.parameters()) > 1_300_000
+
+
+def _py_files(d):
+    for base, _, files in os.walk(d):
+        if "__pycache__" in base:
+            continue
+        for f in files:
+            if f.endswith(".py"):
+                yield os.path.join(base, f)
+
+
+def test_oracle_is_test_infrastructure_only():
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b|from\s+\.+\s*oracle\b", re.M)
+    for f in _py_files(os.path.join(ROOT, "hpcs_amd")):
+        assert not pat.search(open(f).read()), f"{f} imports the oracle"
+    # bench.py may use it only inside cpu_baseline(); __graft_entry__ only inside build()/smoke()
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for m in pat.finditer(src):
+        assert "def cpu_baseline" in src[:m.start()] and "def main" not in src[src.index("def cpu_baseline"):m.start()]
+    assert "/root/reference" not in src
+    for f in list(_py_files(os.path.join(ROOT, "hpcs_amd"))) + [os.path.join(ROOT, "__graft_entry__.py")]:
+        assert "/root/reference" not in open(f).read(), f
+    assert "TEST INFRASTRUCTURE" in open(os.path.join(ROOT, "oracle", "__init__.py")).read()
