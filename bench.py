@@ -59,6 +59,23 @@ def build_step(args, device):
     return step.configure()
 
 
+def pmc_traffic(kernel_substr):
+    """HBM bytes per launch from the committed rocprofv3 PMC summary (scripts/pmc_traffic.py), or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
+    if not os.path.exists(path):
+        return None
+    tab = json.load(open(path))
+    hit = [(v["hbm_bytes_per_launch"], v["launches"]) for k_, v in tab.items() if kernel_substr in k_]
+    if not hit:
+        return None
+    return round(sum(b * n for b, n in hit) / sum(n for _, n in hit))
+
+
+def gemm_bytes(tag):
+    M, Nc, K, no, ni = tag[7], tag[8], tag[9], tag[10], tag[11]
+    return 4.0 * (M * K + (K + M) * Nc * no * ni)
+
+
 def gemm_flops(tag):
     # hpcs_gemm_tn ints: (lda, ldb, sBo, sBi, ldc, sCo, sCi, M, Nc, K, n_outer, n_inner, accumulate)
     M, Nc, K, no, ni = tag[7], tag[8], tag[9], tag[10], tag[11]
@@ -69,7 +86,10 @@ def cpu_baseline(args):
     """The oracle's full step (fwd + loss + bwd + RAdam) on the host cores, on a bounded sample."""
     from oracle import extractor as OE, hyperbolic as OH, metric as OM
     Bc = 4
-    torch.set_num_threads(os.cpu_count())
+    # the GPU box gives one GPU a 16-core share although os.cpu_count() reports the whole host
+    cores = max(1, min(len(os.sched_getaffinity(0)), 16))
+    torch.set_num_threads(cores)
+    print(f"[bench] cpu_baseline: oracle step on {cores} threads ...", file=sys.stderr, flush=True)
     torch.manual_seed(0)
     shapes = OE.param_shapes(args.embedding, 16)
     P = {}
@@ -106,13 +126,16 @@ def cpu_baseline(args):
         (lm + 0.1 * lh).backward()
         OM.radam_step(params, [p_.grad for p_ in params], states, group)
 
+    t0 = time.perf_counter()
     one()                                   # warm-up (also pages torch in)
+    print(f"[bench] cpu_baseline warm-up step {time.perf_counter() - t0:.1f}s", file=sys.stderr, flush=True)
     n = 2
     t0 = time.perf_counter()
-    for _ in range(n):
+    for i in range(n):
         one()
+        print(f"[bench] cpu_baseline step {i + 1}/{n} at {time.perf_counter() - t0:.1f}s", file=sys.stderr, flush=True)
     dt = (time.perf_counter() - t0) / n
-    return {"value": round(Bc / dt, 4), "unit": "point-clouds/s", "cores": os.cpu_count(), "kind": "port",
+    return {"value": round(Bc / dt, 4), "unit": "point-clouds/s", "cores": cores, "kind": "port",
             "sample": f"oracle full step (fwd+loss+bwd+RAdam), B={Bc}, N={args.points}, k={args.k}, E={args.embedding}, "
                       f"C={args.num_class}, {n} timed steps after 1 warm-up, torch {torch.get_num_threads()} threads",
             "s_per_step": round(dt, 3)}
@@ -213,11 +236,14 @@ def main():
         out["roofline"] = {"kernel": "gemm_tn_kernel (hpcs_gemm_tn: channel-mix fwd + data-grad, all shapes)",
                            "bound": "mfma", "achieved": round(gm_flops / gm_time / 1e12, 3), "peak": MFMA_F32_PEAK_TF,
                            "unit": "TFLOP/s", "frac": round(gm_flops / gm_time / 1e12 / MFMA_F32_PEAK_TF, 4),
-                           "traffic": None, "launches": len(gm), "avg_launch_us": round(1e6 * gm_time / len(gm), 2),
+                           "traffic": pmc_traffic("gemm_tn_kernel"),
+                           "algorithmic_bytes_per_launch": round(sum(gemm_bytes(t_) for _, t_ in gm) / len(gm)),
+                           "launches": len(gm), "avg_launch_us": round(1e6 * gm_time / len(gm), 2),
                            "share_of_step": round(gm_time / dt, 4)}
         out["roofline_knn"] = {"kernel": "knn_kernel (hpcs_knn, D=3 and D=63 launches)", "bound": "hbm",
                                "achieved": round(kn_bytes / kn_time / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(kn_bytes / kn_time / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                               "frac": round(kn_bytes / kn_time / 1e9 / HBM_PEAK_GBS, 5), "traffic": pmc_traffic("knn_kernel"),
+                               "algorithmic_bytes_per_launch": round(kn_bytes / len(kn)),
                                "launches": len(kn), "avg_launch_us": round(1e6 * kn_time / len(kn), 2),
                                "fp32_tflops": round(kn_flops / kn_time / 1e12, 3),
                                "note": "arithmetic intensity 36-313 flop/B: bound by VALU selection, not HBM"}

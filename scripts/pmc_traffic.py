@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Summarises rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into per-kernel HBM traffic per launch.
+
+gfx950 corrections (MI355X_MICROARCH.md, HBM section): counters are in KiB; FETCH_SIZE reports exactly 1/2 of the
+bytes of wide (16 B/lane) coalesced streaming reads -> doubled for kernels whose loads are float4-coalesced
+(listed in WIDE); WRITE_SIZE is exact for 16 B/lane streaming stores and float atomics.  Other access widths are
+uncalibrated and are reported uncorrected (flagged).
+
+usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
+"""
+import collections
+import csv
+import json
+import sys
+
+WIDE = ("gemm_tn_kernel", "gemm_nt_kernel")   # contiguous 16 B/lane staging loads
+
+
+def per_kernel(path, counter):
+    agg = collections.defaultdict(lambda: [0.0, 0])
+    disp = collections.defaultdict(float)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        disp[(r["Dispatch_Id"], r["Kernel_Name"])] += float(r["Counter_Value"])
+    for (_, name), v in disp.items():
+        agg[name][0] += v
+        agg[name][1] += 1
+    return agg
+
+
+def short(name):
+    n = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    return n.split("(")[0]
+
+
+def main():
+    fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
+    write = per_kernel(sys.argv[2], "WRITE_SIZE")
+    out = {}
+    for name in sorted(set(fetch) | set(write), key=lambda n: -(fetch.get(n, [0, 1])[0] + write.get(n, [0, 1])[0])):
+        f, nf = fetch.get(name, [0.0, 0])
+        w, nw = write.get(name, [0.0, 0])
+        wide = any(t in name for t in WIDE)
+        fb = f * 1024 * (2 if wide else 1)
+        wb = w * 1024
+        n = max(nf, nw, 1)
+        out[short(name)] = {"launches": n, "fetch_bytes_per_launch": round(fb / n), "write_bytes_per_launch": round(wb / n),
+                            "hbm_bytes_per_launch": round((fb + wb) / n), "fetch_x2_correction": wide}
+    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    for k, v in list(out.items())[:14]:
+        print(f"{v['hbm_bytes_per_launch'] / 1e6:10.1f} MB/launch  x{v['launches']:4d}  {k}")
+
+
+if __name__ == "__main__":
+    main()
