@@ -248,13 +248,14 @@ __global__ __launch_bounds__(1024) void split_reduce_kernel(const float* __restr
     }
 }
 
-constexpr int NT_BM = 64, NT_BN = 64, NT_BKC = 32;
+constexpr int NT_BKC = 32;
 
-struct NtPlan { int tilesM, tilesK, chunk, units_per_batch, nsplit; };
+struct NtPlan { int tile, tilesM, tilesK, chunk, units_per_batch, nsplit; };
 NtPlan nt_plan(int M, int Kx, int Nc, int n_batch) {
     NtPlan p;
-    p.tilesM = hpcs_cdiv(M, NT_BM);
-    p.tilesK = hpcs_cdiv(Kx, NT_BN);
+    p.tile = (M > 512 && Kx > 512) ? 128 : 64;     // measured: 128x128 tiles only pay for the 682x682 layer
+    p.tilesM = hpcs_cdiv(M, p.tile);
+    p.tilesK = hpcs_cdiv(Kx, p.tile);
     p.chunk = 2048;
     p.units_per_batch = hpcs_cdiv(Nc, p.chunk);
     const long units = (long)n_batch * p.units_per_batch;
@@ -320,9 +321,14 @@ extern "C" int hpcs_gemm_nt(const float* G, int ldg, int64_t strideG_o, int64_t 
     const int vecG = (ldg % 4 == 0) && (strideG_o % 4 == 0) && (strideG_i % 4 == 0) && aligned16(G);
     const int vecX = (ldx % 4 == 0) && (strideX_o % 4 == 0) && (strideX_i % 4 == 0) && aligned16(X);
     const long blocks = (long)p.tilesM * p.tilesK * p.nsplit;
-    hipLaunchKernelGGL((gemm_nt_kernel<NT_BM, NT_BN, NT_BKC, 2, 2>), dim3((unsigned)blocks), dim3(256), 0, st, G, ldg,
-                       strideG_o, strideG_i, X, ldx, strideX_o, strideX_i, M, Kx, Nc, n_inner, nb, p.chunk,
-                       p.units_per_batch, p.nsplit, (float*)ws, p.tilesM, p.tilesK, vecG, vecX);
+    if (p.tile == 128)
+        hipLaunchKernelGGL((gemm_nt_kernel<128, 128, NT_BKC, 2, 2>), dim3((unsigned)blocks), dim3(256), 0, st, G, ldg,
+                           strideG_o, strideG_i, X, ldx, strideX_o, strideX_i, M, Kx, Nc, n_inner, nb, p.chunk,
+                           p.units_per_batch, p.nsplit, (float*)ws, p.tilesM, p.tilesK, vecG, vecX);
+    else
+        hipLaunchKernelGGL((gemm_nt_kernel<64, 64, NT_BKC, 2, 2>), dim3((unsigned)blocks), dim3(256), 0, st, G, ldg,
+                           strideG_o, strideG_i, X, ldx, strideX_o, strideX_i, M, Kx, Nc, n_inner, nb, p.chunk,
+                           p.units_per_batch, p.nsplit, (float*)ws, p.tilesM, p.tilesK, vecG, vecX);
     HPCS_CHECK_LAUNCH();
     const int64_t ne = (int64_t)M * Kx;
     hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)hpcs_cdiv(ne, 64)), dim3(1024), 0, st, (const float*)ws,

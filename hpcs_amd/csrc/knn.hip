@@ -7,7 +7,19 @@
 //   score  = ((-sq_j) - (-2*gram)) - sq_i ;  order = (score desc, index asc)
 // This file is compiled with -ffp-contract=off so only the explicit fmaf's fuse.
 //
-// Layout / mapping: one workgroup = one cloud x QT queries (one query per thread).  The cloud's
+// Two kernels:
+//  * knn_mfma_kernel (D = 3 and D = 63, k <= 40: the HPCS shapes).  One workgroup = one cloud x 32 queries, 4 waves.
+//    The Gram tile (32 candidates x 32 queries) is produced by v_mfma_f32_32x32x2_f32 with the candidates as the A
+//    operand (fetched straight from the [D,N] slab: lanes 0-31 read 128 contiguous bytes of row d, lanes 32-63 of
+//    row d+1) and the queries as the B operand (held in registers for the whole kernel).  The f32 MFMA is a
+//    k-ordered fma chain, i.e. exactly the pinned rounding sequence.  Lane l then owns 16 scores of query l&31
+//    (rows (r&3)+8(r>>2)+4(l>>5), increasing in r), which it inserts into its private sorted top-k list.  The
+//    four waves take interleaved candidate tiles, so a query's candidates are spread over 8 lists (4 waves x 2 lane
+//    halves), each visited in ascending index order; a final 8-way merge through LDS (score desc, index asc)
+//    yields the row.  |x|^2 comes from a pre-pass into the caller's workspace.
+//  * knn_kernel (any D, k <= 64): the scalar fallback described next.
+//
+// Fallback layout / mapping: one workgroup = one cloud x QT queries (one query per thread).  The cloud's
 // [D,N] slab is walked in candidate tiles of TC points (256 for D=3, 128 otherwise) staged in LDS as [D+1][TC] (row D = sq):
 // global reads are coalesced along N, LDS reads in the scoring loop are wave-uniform broadcasts.
 // Each thread keeps its sorted top-KK list in registers (static indexing only).
@@ -125,6 +137,130 @@ __global__ __launch_bounds__(QT) void knn_kernel(const float* __restrict__ x, in
     }
 }
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ void knn_sumsq_kernel(const float* __restrict__ x, int D, int N, int64_t total, float* __restrict__ sq) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int64_t b = e / N, j = e % N;
+    sq[e] = sumsq_cascade(x + b * D * N + j, D, N);
+}
+
+constexpr int MQ = 32;         // queries per workgroup (MFMA column block)
+constexpr int MW = 4;          // waves per workgroup = candidate tile interleave
+
+template <int KSTEPS, int KK>
+__global__ __launch_bounds__(MW * 64) void knn_mfma_kernel(const float* __restrict__ x, const float* __restrict__ sq, int D,
+                                                           int N, int k, int64_t* __restrict__ idx) {
+    __shared__ float lval[MQ][2 * MW][KK];
+    __shared__ int lidx[MQ][2 * MW][KK];
+    const int tiles_q = (N + MQ - 1) / MQ;
+    const int b = blockIdx.x / tiles_q;
+    const int q0 = (blockIdx.x % tiles_q) * MQ;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lr = lane & 31, lk = lane >> 5;
+    const float* xb = x + (int64_t)b * D * N;
+    const float* sqb = sq + (int64_t)b * N;
+
+    // B operand: B[k][j] = x[d = 2*kk + lk][query q0 + lr]
+    const int qi = q0 + lr;
+    const bool qok = qi < N;
+    float bq[KSTEPS];
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; ++kk) {
+        const int d = 2 * kk + lk;
+        bq[kk] = (qok && d < D) ? xb[(int64_t)d * N + qi] : 0.f;
+    }
+    const float sq_i = qok ? sqb[qi] : 0.f;
+
+    float bv[KK];
+    int bi[KK];
+#pragma unroll
+    for (int m = 0; m < KK; ++m) {
+        bv[m] = -INFINITY;
+        bi[m] = 0x7fffffff;
+    }
+
+    const int ntile = (N + 31) / 32;
+    for (int t = w; t < ntile; t += MW) {
+        const int c0 = t * 32;
+        const int ci = c0 + lr;
+        const bool cok = ci < N;
+        float af[KSTEPS];
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) {
+            const int d = 2 * kk + lk;
+            af[kk] = (cok && d < D) ? xb[(int64_t)d * N + ci] : 0.f;
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk], bq[kk], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = c0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            const float sq_j = j < N ? sqb[j] : 0.f;
+            const float inner = -2.0f * acc[r];
+            const float tt = (-sq_j) - inner;
+            const float sc = j < N ? tt - sq_i : -INFINITY;
+            if (__any(sc > bv[KK - 1])) topk_insert<KK>(bv, bi, sc, j);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < KK; ++m) {
+        lval[lr][2 * w + lk][m] = bv[m];
+        lidx[lr][2 * w + lk][m] = bi[m];
+    }
+    __syncthreads();
+    // 8-way merge of the sorted sub-lists: one thread per query
+    if (threadIdx.x < MQ && q0 + (int)threadIdx.x < N) {
+        const int q = threadIdx.x;
+        int head[2 * MW];
+#pragma unroll
+        for (int u = 0; u < 2 * MW; ++u) head[u] = 0;
+        int64_t* o = idx + ((int64_t)b * N + q0 + q) * k;
+        for (int m = 0; m < k; ++m) {
+            float best = -INFINITY;
+            int bidx = 0x7fffffff, bu = 0;
+#pragma unroll
+            for (int u = 0; u < 2 * MW; ++u) {
+                const int h = head[u];
+                const float v = h < KK ? lval[q][u][h] : -INFINITY;
+                const int i2 = h < KK ? lidx[q][u][h] : 0x7fffffff;
+                if (v > best || (v == best && i2 < bidx)) {
+                    best = v;
+                    bidx = i2;
+                    bu = u;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2 * MW; ++u) head[u] += (u == bu) ? 1 : 0;
+            o[m] = bidx;
+        }
+    }
+}
+
+template <int KSTEPS>
+int launch_knn_mfma(const float* x, const float* sq, int B, int D, int N, int k, int64_t* idx, hipStream_t st) {
+    const int tiles_q = (N + MQ - 1) / MQ;
+    const dim3 grid((unsigned)(B * tiles_q));
+#define HPCS_KNNM_CASE(KK)                                                                                   \
+    if (k <= KK) {                                                                                            \
+        hipLaunchKernelGGL((knn_mfma_kernel<KSTEPS, KK>), grid, dim3(MW * 64), 0, st, x, sq, D, N, k, idx);   \
+        return HPCS_OK;                                                                                       \
+    }
+    HPCS_KNNM_CASE(4)
+    HPCS_KNNM_CASE(8)
+    HPCS_KNNM_CASE(10)
+    HPCS_KNNM_CASE(16)
+    HPCS_KNNM_CASE(20)
+    HPCS_KNNM_CASE(32)
+    HPCS_KNNM_CASE(40)
+#undef HPCS_KNNM_CASE
+    return HPCS_ERR_UNSUPPORTED;
+}
+
 template <int DT, int TC>
 int launch_knn(const float* x, int B, int D, int N, int k, int64_t* idx, hipStream_t st) {
     const int tiles_q = (N + QT - 1) / QT;
@@ -153,19 +289,33 @@ int launch_knn(const float* x, int B, int D, int N, int k, int64_t* idx, hipStre
 
 }  // namespace
 
-extern "C" int hpcs_knn(const float* x, int B, int D, int N, int k, int64_t* idx, hpcs_stream_t stream) {
+extern "C" size_t hpcs_knn_workspace(int B, int N) {
+    if (B <= 0 || N <= 0) return 64;
+    return (size_t)B * N * sizeof(float);
+}
+
+extern "C" int hpcs_knn(const float* x, int B, int D, int N, int k, int64_t* idx, void* ws, size_t ws_bytes,
+                        hpcs_stream_t stream) {
     if (!x || !idx) return HPCS_ERR_NULL;
     if (B < 0 || D <= 0 || N <= 0 || k <= 0 || k > N) return HPCS_ERR_SHAPE;
     if (k > 64) return HPCS_ERR_UNSUPPORTED;
     if (B == 0) return HPCS_OK;
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if (D == 3)
+    if ((D == 3 || D == 63) && k <= 40 && ws) {
+        if (ws_bytes < hpcs_knn_workspace(B, N)) return HPCS_ERR_WORKSPACE;
+        float* sq = (float*)ws;
+        const int64_t total = (int64_t)B * N;
+        hipLaunchKernelGGL(knn_sumsq_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, D, N, total, sq);
+        HPCS_CHECK_LAUNCH();
+        rc = D == 3 ? launch_knn_mfma<2>(x, sq, B, D, N, k, idx, st) : launch_knn_mfma<32>(x, sq, B, D, N, k, idx, st);
+    } else if (D == 3) {
         rc = launch_knn<3, 256>(x, B, D, N, k, idx, st);
-    else if (D == 63)
+    } else if (D == 63) {
         rc = launch_knn<63, 128>(x, B, D, N, k, idx, st);
-    else
+    } else {
         rc = launch_knn<0, 128>(x, B, D, N, k, idx, st);
+    }
     if (rc != HPCS_OK) return rc;
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;

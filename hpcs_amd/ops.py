@@ -86,7 +86,9 @@ def knn(x, k):
     if not 0 < k <= N:
         raise ValueError(f"k={k} must be in 1..N={N}")
     idx = torch.empty(B, N, k, dtype=torch.int64, device=x.device)
-    call("hpcs_knn", x, B, D, N, k, idx)
+    nbytes = call("hpcs_knn_workspace", B, N)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+    call("hpcs_knn", x, B, D, N, k, idx, ws, nbytes, tag=(B, D, N, k))
     return idx
 
 

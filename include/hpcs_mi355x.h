@@ -40,7 +40,10 @@ int hpcs_version(void);
 /* ---- a1: knn(x, k)  hpcs/nn/dgcnn/utils/vn_dgcnn_util.py:4-10 ------------------------------
  * x [B,D,N] -> idx [B,N,k] int64: the k largest of  (-|xj|^2 - (-2 xi.xj)) - |xi|^2  per row,
  * nearest first, ties by ascending index.  Rounding sequence = torch CPU. k <= 64. */
-int hpcs_knn(const float* x, int B, int D, int N, int k, int64_t* idx, hpcs_stream_t stream);
+/* ws (hpcs_knn_workspace bytes, may be NULL): |x|^2 scratch that enables the MFMA kernel for D in {3,63}, k<=40. */
+size_t hpcs_knn_workspace(int B, int N);
+int hpcs_knn(const float* x, int B, int D, int N, int k, int64_t* idx, void* ws, size_t ws_bytes,
+             hpcs_stream_t stream);
 
 /* ---- a2: get_graph_feature  hpcs/nn/dgcnn/utils/vn_dgcnn_util.py:13-41 ----------------------
  * x [B,C,3,N], idx [B,N,k] (cloud-local) -> out [B,2C,3,N,k] = (x[nbr]-x[ctr], x[ctr]).

@@ -27,10 +27,11 @@ def test_argument_validation_without_gpu():
     L = _lib.lib()
     f = L.hpcs_knn
     f.restype = ctypes.c_int
-    f.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
-    assert f(None, 1, 3, 8, 2, None, None) == -4            # HPCS_ERR_NULL
-    assert f(1, 1, 3, 8, 9, 1, None) == -1                   # k > N: HPCS_ERR_SHAPE
-    assert f(1, 1, 3, 128, 65, 1, None) == -2                # k > 64: HPCS_ERR_UNSUPPORTED
+    f.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                  ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    assert f(None, 1, 3, 8, 2, None, None, 0, None) == -4            # HPCS_ERR_NULL
+    assert f(1, 1, 3, 8, 9, 1, None, 0, None) == -1                   # k > N: HPCS_ERR_SHAPE
+    assert f(1, 1, 3, 128, 65, 1, None, 0, None) == -2                # k > 64: HPCS_ERR_UNSUPPORTED
     g = L.hpcs_gemm_nt_workspace
     g.restype = ctypes.c_size_t
     g.argtypes = [ctypes.c_int] * 5

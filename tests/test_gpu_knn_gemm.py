@@ -14,7 +14,12 @@ dev = "cuda"
 def hip_knn(x, k):
     B, D, N = x.shape
     idx = torch.empty(B, N, k, dtype=torch.int64, device=dev)
-    _lib.call("hpcs_knn", x.to(dev).contiguous(), B, D, N, k, idx)
+    nbytes = _lib.call("hpcs_knn_workspace", B, N)
+    ws = torch.empty(nbytes // 4, device=dev)
+    _lib.call("hpcs_knn", x.to(dev).contiguous(), B, D, N, k, idx, ws, nbytes)
+    idx2 = torch.empty_like(idx)                      # scalar fallback kernel (no workspace) must agree
+    _lib.call("hpcs_knn", x.to(dev).contiguous(), B, D, N, k, idx2, None, 0)
+    assert torch.equal(idx, idx2)
     return idx.cpu()
 
 
@@ -41,9 +46,9 @@ def test_knn_errors():
     x = torch.zeros(1, 3, 16, device=dev)
     idx = torch.empty(1, 16, 20, dtype=torch.int64, device=dev)
     with pytest.raises(_lib.HpcsNativeError):
-        _lib.call("hpcs_knn", x, 1, 3, 16, 20, idx)       # k > N
+        _lib.call("hpcs_knn", x, 1, 3, 16, 20, idx, None, 0)       # k > N
     with pytest.raises(_lib.HpcsNativeError):
-        _lib.call("hpcs_knn", torch.zeros(1, 3, 16), 1, 3, 16, 4, idx)   # CPU tensor: no fallback
+        _lib.call("hpcs_knn", torch.zeros(1, 3, 16), 1, 3, 16, 4, idx, None, 0)   # CPU tensor: no fallback
 
 
 @pytest.mark.parametrize("M,K,Nc,nb", [(21, 2, 300, 3), (42, 42, 1024, 2), (341, 63, 3 * 256, 2),
