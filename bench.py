@@ -159,6 +159,8 @@ def main():
     from hpcs_amd.dp import broadcast_parameters, init_distributed
     import torch.distributed as dist
 
+    # os.cpu_count() reports the whole host (256) while one GPU's share is 16 cores: cap torch's host threads
+    torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 16)))
     rank, local, world = init_distributed()
     if world != args.gpus:
         if world == 1 and args.gpus > 1:

@@ -250,7 +250,9 @@ template <int EPL, bool BWD, bool FAST>
 __global__ __launch_bounds__(TPB) void hyphc_kernel(const float* __restrict__ xn, int E, const int64_t* __restrict__ a,
                                                     const int64_t* __restrict__ p, const int64_t* __restrict__ n,
                                                     const int64_t* __restrict__ count, int64_t T_cap,
-                                                    const float* __restrict__ scale, float temperature,
+                                                    const float* __restrict__ scale, float temperature, float margin,
+                                                    int kind, const int64_t* __restrict__ norm_count,
+                                                    unsigned long long* __restrict__ kept_out,
                                                     const float* __restrict__ gloss, double* __restrict__ loss_sum,
                                                     float* __restrict__ gxn, double* __restrict__ gscale, unsigned perm_mul) {
     __shared__ double red[16];
@@ -260,8 +262,13 @@ __global__ __launch_bounds__(TPB) void hyphc_kernel(const float* __restrict__ xn
     const float sc = fminf(fmaxf(sraw, 1e-4f), 1.f);
     const bool s_live = sraw >= 1e-4f && sraw <= 1.f;         // torch.clamp passes the gradient inside the range only
     const float inv_t = 1.f / temperature;
+    // kind >= 0: the miner's margin filter is applied inline (no compaction pass); the mean is over kept triplets
     float up = 0.f;
-    if (BWD) up = T > 0 ? (float)((double)(*gloss) / (double)T) : 0.f;
+    if (BWD) {
+        const int64_t Tn = norm_count ? *norm_count : T;
+        up = Tn > 0 ? (float)((double)(*gloss) / (double)Tn) : 0.f;
+    }
+    unsigned kept = 0;
     const int lane = threadIdx.x & 63;
     const int s = threadIdx.x % SUB, g = threadIdx.x / SUB;
     const int sub0 = lane & ~(SUB - 1);
@@ -278,7 +285,7 @@ __global__ __launch_bounds__(TPB) void hyphc_kernel(const float* __restrict__ xn
 
     for (int i = 0; i < RUN; ++i) {
         const int64_t t = base + i;
-        const bool live = t < T;
+        bool live = t < T;
         const int64_t ia = live ? a[t] : 0, ip = live ? p[t] : 0, in = live ? n[t] : 0;
         float av[EPL], pv[EPL], nv[EPL];
         float d1 = 0.f, d2 = 0.f, d3 = 0.f;
@@ -296,6 +303,11 @@ __global__ __launch_bounds__(TPB) void hyphc_kernel(const float* __restrict__ xn
         d1 = sub_sum(d1);
         d2 = sub_sum(d2);
         d3 = sub_sum(d3);
+        if (kind >= 0) {
+            const float tm = 0.5f * (1.f + d1) - 0.5f * (1.f + d2);
+            live = live && keep_rule(tm, margin, kind);
+            if (!BWD && live && s == 0) ++kept;
+        }
         // lane s (<3) of the group evaluates similarity s; lanes >= 3 shadow similarity 2
         const float my_dot = s == 0 ? d1 : (s == 1 ? d2 : d3);
         const LcaF L = lca_of_dot(sc, my_dot);
@@ -376,12 +388,17 @@ __global__ __launch_bounds__(TPB) void hyphc_kernel(const float* __restrict__ xn
     }
     const double tot = hpcs_block_sum<double>(acc, red);
     if (threadIdx.x == 0 && tot != 0.0) atomicAdd(BWD ? gscale : loss_sum, tot);
+    if (!BWD && kept_out) {
+        const double kt = hpcs_block_sum<double>((double)kept, red);
+        if (threadIdx.x == 0 && kt != 0.0) atomicAdd(kept_out, (unsigned long long)kt);
+    }
 }
 
 template <bool BWD>
 int launch_hyphc(const float* xn, int E, const int64_t* a, const int64_t* p, const int64_t* n, const int64_t* count,
-                 int64_t T_cap, const float* scale, float temperature, const float* gloss, double* loss_sum, float* gxn,
-                 double* gscale, hipStream_t st) {
+                 int64_t T_cap, const float* scale, float temperature, float margin, int kind, const int64_t* norm_count,
+                 unsigned long long* kept_out, const float* gloss, double* loss_sum, float* gxn, double* gscale,
+                 hipStream_t st) {
     const int64_t per_block = (int64_t)TRIP_PER_PASS * RUN;
     const dim3 grid((unsigned)((T_cap + per_block - 1) / per_block));
     unsigned perm_mul = 1;
@@ -394,10 +411,10 @@ int launch_hyphc(const float* xn, int E, const int64_t* a, const int64_t* p, con
     if (E <= 8 * EPL) {                                                                                               \
         if (BWD && E == 8 * EPL && EPL >= 2)                                                                          \
             hipLaunchKernelGGL((hyphc_kernel<EPL, BWD, true>), grid, dim3(TPB), 0, st, xn, E, a, p, n, count, T_cap, \
-                               scale, temperature, gloss, loss_sum, gxn, gscale, perm_mul);                           \
+                               scale, temperature, margin, kind, norm_count, kept_out, gloss, loss_sum, gxn, gscale, perm_mul); \
         else                                                                                                          \
             hipLaunchKernelGGL((hyphc_kernel<EPL, BWD, false>), grid, dim3(TPB), 0, st, xn, E, a, p, n, count, T_cap,\
-                               scale, temperature, gloss, loss_sum, gxn, gscale, perm_mul);                           \
+                               scale, temperature, margin, kind, norm_count, kept_out, gloss, loss_sum, gxn, gscale, perm_mul); \
         return HPCS_OK;                                                                                               \
     }
     HPCS_HYPHC_CASE(1)
@@ -629,26 +646,30 @@ extern "C" int hpcs_triplet_filter(const float* xn, int E, const int64_t* a, con
 }
 
 extern "C" int hpcs_hyphc_fwd(const float* xn, int E, const int64_t* a, const int64_t* p, const int64_t* n,
-                              const int64_t* count, int64_t T_cap, const float* scale, float temperature, double* loss_sum,
-                              hpcs_stream_t stream) {
+                              const int64_t* count, int64_t T_cap, const float* scale, float temperature, float margin,
+                              int kind, double* loss_sum, int64_t* kept, hpcs_stream_t stream) {
     if (!xn || !a || !p || !n || !count || !scale || !loss_sum) return HPCS_ERR_NULL;
-    if (E <= 0 || T_cap < 0 || !(temperature > 0.f)) return HPCS_ERR_SHAPE;
+    if (E <= 0 || T_cap < 0 || !(temperature > 0.f) || kind > 3 || (kind >= 0 && !kept)) return HPCS_ERR_SHAPE;
     if (hipMemsetAsync(loss_sum, 0, sizeof(double), ST) != hipSuccess) return HPCS_ERR_HIP;
+    if (kept && hipMemsetAsync(kept, 0, sizeof(int64_t), ST) != hipSuccess) return HPCS_ERR_HIP;
     if (T_cap == 0) return HPCS_OK;
-    const int rc = launch_hyphc<false>(xn, E, a, p, n, count, T_cap, scale, temperature, nullptr, loss_sum, nullptr, nullptr, ST);
+    const int rc = launch_hyphc<false>(xn, E, a, p, n, count, T_cap, scale, temperature, margin, kind, nullptr,
+                                       (unsigned long long*)kept, nullptr, loss_sum, nullptr, nullptr, ST);
     if (rc) return rc;
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;
 }
 
 extern "C" int hpcs_hyphc_bwd(const float* xn, int E, const int64_t* a, const int64_t* p, const int64_t* n,
-                              const int64_t* count, int64_t T_cap, const float* scale, float temperature,
-                              const float* gloss, float* gxn, double* gscale, hpcs_stream_t stream) {
+                              const int64_t* count, int64_t T_cap, const float* scale, float temperature, float margin,
+                              int kind, const int64_t* norm_count, const float* gloss, float* gxn, double* gscale,
+                              hpcs_stream_t stream) {
     if (!xn || !a || !p || !n || !count || !scale || !gloss || !gxn || !gscale) return HPCS_ERR_NULL;
-    if (E <= 0 || T_cap < 0 || !(temperature > 0.f)) return HPCS_ERR_SHAPE;
+    if (E <= 0 || T_cap < 0 || !(temperature > 0.f) || kind > 3 || (kind >= 0 && !norm_count)) return HPCS_ERR_SHAPE;
     if (hipMemsetAsync(gscale, 0, sizeof(double), ST) != hipSuccess) return HPCS_ERR_HIP;
     if (T_cap == 0) return HPCS_OK;
-    const int rc = launch_hyphc<true>(xn, E, a, p, n, count, T_cap, scale, temperature, gloss, nullptr, gxn, gscale, ST);
+    const int rc = launch_hyphc<true>(xn, E, a, p, n, count, T_cap, scale, temperature, margin, kind, norm_count, nullptr,
+                                      gloss, nullptr, gxn, gscale, ST);
     if (rc) return rc;
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;

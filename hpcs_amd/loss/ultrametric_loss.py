@@ -44,33 +44,46 @@ class L2RowsFn(torch.autograd.Function):
         return gx
 
 
+_KIND = {None: -1, "all": 0, "easy": 1, "semihard": 2, "hard": 3}
+
+
 class HypHCFn(torch.autograd.Function):
-    """mean over mined triplets of sum(w) - sum(w*softmax(d/temp)), plus the closed-form mean similarity."""
+    """mean over mined triplets of sum(w) - sum(w*softmax(d/temp)), plus the closed-form mean similarity.
+
+    kind=None: (a,p,n,count) are already mined.  kind in {"all","easy","semihard","hard"}: (a,p,n) are the sampled
+    triplets and the miner's margin rule is evaluated inside the loss kernels (no compaction pass).
+    """
 
     @staticmethod
-    def forward(ctx, xn, scale, a, p, n, count, temperature):
+    def forward(ctx, xn, scale, a, p, n, count, temperature, margin, kind):
         M, E = xn.shape
         dev = xn.device
         loss_sum = torch.empty(1, dtype=torch.float64, device=dev)
-        call("hpcs_hyphc_fwd", xn, E, a, p, n, count, a.numel(), scale, temperature, loss_sum)
+        kid = _KIND[kind]
+        kept = torch.empty(1, dtype=torch.int64, device=dev) if kid >= 0 else None
+        call("hpcs_hyphc_fwd", xn, E, a, p, n, count, a.numel(), scale, temperature, margin, kid, loss_sum, kept)
+        norm = kept if kid >= 0 else count
         colsum = torch.empty(E, dtype=torch.float64, device=dev)
         call("hpcs_colsum", xn, M, E, colsum)
         mean_sim = 0.5 + 0.5 * (colsum * colsum).sum() / float(M * M)
-        out = loss_sum[0] / count[0].double() + mean_sim
-        ctx.save_for_backward(xn, scale, a, p, n, count, colsum)
-        ctx.temperature = temperature
+        out = loss_sum[0] / norm[0].double() + mean_sim
+        ctx.save_for_backward(xn, scale, a, p, n, count, colsum, norm)
+        ctx.cfg = (temperature, margin, kid)
+        ctx.kept = norm
         return out.float()
 
     @staticmethod
     def backward(ctx, g):
-        xn, scale, a, p, n, count, colsum = ctx.saved_tensors
+        xn, scale, a, p, n, count, colsum, norm = ctx.saved_tensors
+        temperature, margin, kid = ctx.cfg
         M, E = xn.shape
         g32 = g.reshape(1).contiguous().float()
         # d mean_sim / d xn_i = colsum / M^2 (same row for every i)
         gxn = ((colsum / float(M * M)).float() * g32).unsqueeze(0).repeat(M, 1).contiguous()
         gscale = torch.empty(1, dtype=torch.float64, device=xn.device)
-        call("hpcs_hyphc_bwd", xn, E, a, p, n, count, a.numel(), scale, ctx.temperature, g32, gxn, gscale)
-        return gxn, gscale.float().view_as(scale), None, None, None, None, None
+        call("hpcs_hyphc_bwd", xn, E, a, p, n, count, a.numel(), scale, temperature, margin, kid,
+             norm if kid >= 0 else None, g32, gxn, gscale)
+        return gxn, gscale.float().view_as(scale), None, None, None, None, None, None, None
 
 
 class CosFaceFn(torch.autograd.Function):
@@ -126,7 +139,7 @@ class MetricHyperbolicLoss(torch.nn.Module):
     def __init__(self, margin: float = 1.0, t_per_anchor: int = 50, fraction: float = 1.2,
                  scale: Union[float, torch.Tensor, torch.nn.Parameter] = 1e-3, temperature: float = 0.05,
                  anneal_factor: float = 0.5, num_class: int = 4, embedding_size: int = 4, cosface: bool = True,
-                 miner: bool = False, rng: str = "host"):
+                 miner: bool = False, rng: str = "host", fused_filter: bool = False):
         super().__init__()
         self.margin = margin
         self.t_per_anchor = t_per_anchor
@@ -138,6 +151,7 @@ class MetricHyperbolicLoss(torch.nn.Module):
         self.embedding_size = embedding_size
         self.cosface = cosface
         self.miner = miner
+        self.fused_filter = fused_filter        # True: hyp_miner's margin filter runs inside the loss kernels
         self.distance_sim = CosineSimilarity()
         if self.miner:
             self.hyp_miner = RandomTripletMarginMiner(distance=self.distance_sim, margin=0, t_per_anchor=t_per_anchor,
@@ -169,15 +183,26 @@ class MetricHyperbolicLoss(torch.nn.Module):
     def compute_hyp(self, x_poincare, labels, plan=None, triplets=None, xn=None):
         if xn is None:
             xn = L2RowsFn.apply(x_poincare)
+        kind, margin = None, 0.0
         if triplets is None:
-            if self.miner:
+            if self.miner and self.fused_filter:
+                # sample only; the 'easy'/margin-0 rule of hyp_miner is evaluated inside the loss kernels
+                from ..miner.loss_and_miner_utils import TripletPlan, sample_with_plan
+                m = self.hyp_miner
+                if plan is None:
+                    plan = TripletPlan.from_labels(labels, m.t_per_anchor, m.fraction)
+                m.seed += 1
+                a, p, n = sample_with_plan(labels, plan, rng=m.rng, seed=m.seed)
+                triplets = (a, p, n, torch.full((1,), a.numel(), dtype=torch.int64, device=xn.device))
+                kind, margin = m.type_of_triplets, float(m.margin)
+            elif self.miner:
                 triplets = self.hyp_miner.mine_device(x_poincare, labels, plan=plan, xn=xn.detach())
             else:
                 triplets = self.get_triplets(x_poincare.shape[0], x_poincare.device)
         a, p, n, count = triplets
         self.last_triplets = triplets
         scale = self._scale_tensor(xn)
-        return HypHCFn.apply(xn, scale, a, p, n, count, float(self.temperature))
+        return HypHCFn.apply(xn, scale, a, p, n, count, float(self.temperature), margin, kind)
 
     def get_logits(self, embeddings, labels):
         if not hasattr(self, "loss_cosface"):

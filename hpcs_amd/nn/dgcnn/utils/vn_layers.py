@@ -68,11 +68,12 @@ class VNLinearLeakyReLU(nn.Module):                            # vn_layers.py:48
         self.batchnorm = VNBatchNorm(out_channels, dim=dim)
         self.map_to_dir = nn.Linear(in_channels, 1 if share_nonlinearity else out_channels, bias=False)
 
-    def forward(self, x, pool_k=0):
-        """pool_k>0 additionally averages over the trailing dim of size pool_k (fused mean_pool)."""
+    def forward(self, x, pool_k=0, xconst=None):
+        """pool_k>0 additionally averages over the trailing dim of size pool_k (fused mean_pool).
+        xconst [B,Cc,3]: the last Cc input channels given as per-cloud constants instead of expanded over N."""
         bn = self.batchnorm.bn
         out = ops.vn_layer(_flat(x), self.map_to_feat.weight, self.map_to_dir.weight, bn.weight, bn.bias, bn.running_mean,
-                           bn.running_var, self.training, slope=self.negative_slope, pool_k=pool_k)
+                           bn.running_var, self.training, slope=self.negative_slope, pool_k=pool_k, xconst=xconst)
         if self.training:
             bn.num_batches_tracked.add_(1)
         return out
@@ -110,8 +111,8 @@ class VNStdFeature(nn.Module):                                 # vn_layers.py:15
                                      negative_slope=negative_slope)
         self.vn_lin = nn.Linear(in_channels // 4, 3, bias=False)
 
-    def frame(self, x):
-        z = self.vn2(self.vn1(x))
+    def frame(self, x, xconst=None):
+        z = self.vn2(self.vn1(x, xconst=xconst))
         z = ops.chan_mix(z, self.vn_lin.weight)        # [B,3,3,N]
         return z.transpose(1, 2).contiguous()
 

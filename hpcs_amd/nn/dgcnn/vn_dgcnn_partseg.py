@@ -6,6 +6,7 @@ forward contract: x [B,3,N] fp32, l [B,num_categories] one-hot -> [B,N,out_featu
 Differences in HOW (not what) it computes (DESIGN.md "Extractor"):
   * kNN is the fused score+top-k kernel (no N x N matrix);
   * mean_pool is fused into the last VN layer of each EdgeConv block;
+  * std_feature.vn1's 341 mean channels (constant over N, :82-83) enter its GEMM as a per-cloud row bias;
   * conv8's 2110 channels that are constant over N (global max feature + category code) are applied as a
     per-cloud row bias instead of being repeated N times (vn_dgcnn_partseg.py:92-95).
 """
@@ -98,9 +99,11 @@ class VN_DGCNN_partseg(nn.Module):
         x3 = self._edge_block(x2, (self.conv5,), self.pool3)
         x123 = torch.cat((x1, x2, x3), dim=1)                                   # [B,63,3,N]
 
-        g = self.conv6(x123)                                                    # [B,341,3,N]
-        g = ops.ConcatMeanFn.apply(g)                                           # [B,682,3,N]
-        z0 = self.std_feature.frame(g)                                          # [B,3,3,N]
+        g6 = self.conv6(x123)                                                   # [B,341,3,N]
+        gbar = ops.RowMeanFn.apply(g6)                                          # [B,341,3] mean over N
+        # vn1 sees cat(g6, mean expanded) (:82-83): the N-constant half enters its GEMM as a row bias
+        z0 = self.std_feature.frame(g6, xconst=gbar)                            # [B,3,3,N]
+        g = ops.ConcatMeanFn.apply(g6)                                          # [B,682,3,N] (for the projection)
         g_std = ops.FrameProjectFn.apply(g, z0)
         loc = ops.FrameProjectFn.apply(x123, z0).view(B, -1, N)                 # [B,189,N]
         glob = ops.RowMaxFn.apply(g_std.view(B, -1, N))                         # [B,2046]

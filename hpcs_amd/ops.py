@@ -157,15 +157,26 @@ def chan_mix(x, W, rowbias=None):
 
 
 # ------------------------------------------------------------------------------------------------ a3
+def _gemm_inner3(W, x, B, K, L, rowbias3):
+    """PD[b,:,a,:] = W @ x[b,:,a,:] + rowbias3[b,a,:]  -- walks a [B,K,3,L] tensor as 3B matrices of L columns."""
+    M = W.shape[0]
+    out = torch.empty(B * M * 3 * L, device=x.device, dtype=torch.float32)
+    At = _as_At(W)
+    call("hpcs_gemm_tn", At, At.shape[1], x, 3 * L, K * 3 * L, L, out, 3 * L, M * 3 * L, L, M, L, K, B, 3, rowbias3, 0)
+    return out
+
+
 class VNLayerFn(torch.autograd.Function):
     """p = Wf x ; [VNBatchNorm] ; [VN-LeakyReLU with d = Wd x] ; [mean over pool_k consecutive positions].
 
     x [B,Cin,3,*S] -> [B,Cout,3,*S] (or [B,Cout,3,S0] when pool_k = S1 > 0).
     One stacked GEMM produces PD = [Wf;Wd] x; backward recomputes the point-wise state from PD.
+    xconst [B,Cc,3] (optional): Cc further input channels that are constant over the positions (the weights' last Cc
+    columns); they enter as a per-(cloud, xyz) row bias instead of being expanded (vn_dgcnn_partseg.py:82-83).
     """
 
     @staticmethod
-    def forward(ctx, x, Wf, Wd, gamma, beta, rmean, rvar, training, slope, pool_k, flags):
+    def forward(ctx, x, Wf, Wd, gamma, beta, rmean, rvar, training, slope, pool_k, flags, xconst):
         x = _f32c(x)
         B, Cin = x.shape[0], x.shape[1]
         L = x[0, 0, 0].numel()
@@ -174,7 +185,17 @@ class VNLayerFn(torch.autograd.Function):
         Wcat = torch.cat([Wf, Wd], 0) if Cd else Wf
         Wcat = _f32c(Wcat)
         Ctot = Cout + Cd
-        PD = gemm_WX(Wcat, x, B, Cin, 3 * L)
+        Cc = 0
+        if xconst is not None:
+            xconst = _f32c(xconst)
+            Cc = xconst.shape[1]
+            Wx = Wcat[:, :Cin].contiguous()
+            Wc = Wcat[:, Cin:].contiguous()
+            bias = gemm_WX(Wc, xconst, B, Cc, 3).view(B, Ctot, 3).permute(0, 2, 1).contiguous()     # [B,3,Ctot]
+            PD = _gemm_inner3(Wx, x, B, Cin, L, bias)
+        else:
+            Wx, Wc = Wcat, None
+            PD = gemm_WX(Wcat, x, B, Cin, 3 * L)
         dev = x.device
         mean = rstd = None
         if flags & VN_BN:
@@ -190,14 +211,14 @@ class VNLayerFn(torch.autograd.Function):
         else:
             out = torch.empty(B, Cout, *x.shape[2:], device=dev)
         call("hpcs_vn_apply_fwd", PD, mean, rstd, gamma, beta, B, Cout, Cd, L, pool_k, slope, flags, out)
-        ctx.save_for_backward(x, Wcat, PD, mean, rstd, gamma, beta)
-        ctx.cfg = (B, Cin, Cout, Cd, L, pool_k, slope, flags, bool(training))
+        ctx.save_for_backward(x, Wx, Wc, xconst, PD, mean, rstd, gamma, beta)
+        ctx.cfg = (B, Cin, Cc, Cout, Cd, L, pool_k, slope, flags, bool(training))
         return out
 
     @staticmethod
     def backward(ctx, g):
-        x, Wcat, PD, mean, rstd, gamma, beta = ctx.saved_tensors
-        B, Cin, Cout, Cd, L, pool_k, slope, flags, training = ctx.cfg
+        x, Wx, Wc, xconst, PD, mean, rstd, gamma, beta = ctx.saved_tensors
+        B, Cin, Cc, Cout, Cd, L, pool_k, slope, flags, training = ctx.cfg
         g = _f32c(g)
         dev = g.device
         Ctot = Cout + Cd
@@ -208,22 +229,30 @@ class VNLayerFn(torch.autograd.Function):
         GPD = torch.empty(B * Ctot * 3 * L, device=dev)
         call("hpcs_vn_bwd_apply", PD, g, mean, rstd, gamma, beta, red, 1 if training else 0, B, Cout, Cd, L, pool_k, slope,
              flags, GPD)
-        gx = gW = gWd = ggamma = gbeta = None
+        gx = gW = gWd = ggamma = gbeta = gxc = None
         if ctx.needs_input_grad[0]:
-            gx = gemm_WtG(Wcat, GPD, B, Ctot, 3 * L).view_as(x)
+            gx = gemm_WtG(Wx, GPD, B, Ctot, 3 * L).view_as(x)
+        S = None
+        if Cc:
+            S = torch.empty(B, Ctot, 3, device=dev)
+            call("hpcs_rowsum", GPD, B * Ctot * 3, L, 1.0, S)
+            if ctx.needs_input_grad[11]:
+                gxc = gemm_WtG(Wc, S, B, Ctot, 3).view(B, Cc, 3)
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             gWcat = gemm_GXt(GPD, x, B, Ctot, Cin, 3 * L)
+            if Cc:
+                gWcat = torch.cat([gWcat, gemm_GXt(S, xconst, B, Ctot, Cc, 3)], dim=1)
             gW = gWcat[:Cout]
             gWd = gWcat[Cout:] if Cd else None
         if flags & VN_BN:
             gbeta = red[:Cout].float()
             ggamma = red[Cout:].float()
-        return gx, gW, gWd, ggamma, gbeta, None, None, None, None, None, None
+        return gx, gW, gWd, ggamma, gbeta, None, None, None, None, None, None, gxc
 
 
-def vn_layer(x, Wf, Wd, gamma, beta, rmean, rvar, training, slope=0.2, pool_k=0, flags=VN_BN | VN_LRELU):
+def vn_layer(x, Wf, Wd, gamma, beta, rmean, rvar, training, slope=0.2, pool_k=0, flags=VN_BN | VN_LRELU, xconst=None):
     _need_cuda(x, Wf)
-    return VNLayerFn.apply(x, Wf, Wd, gamma, beta, rmean, rvar, training, slope, pool_k, flags)
+    return VNLayerFn.apply(x, Wf, Wd, gamma, beta, rmean, rvar, training, slope, pool_k, flags, xconst)
 
 
 # ------------------------------------------------------------------------------------------------ Conv1d heads

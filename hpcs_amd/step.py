@@ -15,13 +15,15 @@ from .optim import RAdam
 
 
 def random_rotations(B, device, generator=None):
-    """Haar-uniform SO(3) matrices [B,3,3] from sign-fixed QR of Gaussian matrices (on device)."""
-    g = torch.randn(B, 3, 3, device=device, generator=generator)
-    q, r = torch.linalg.qr(g)
-    q = q * torch.sign(torch.diagonal(r, dim1=-2, dim2=-1)).unsqueeze(-2)
-    det = torch.linalg.det(q)
-    q[:, :, 0] = q[:, :, 0] * det.unsqueeze(-1)
-    return q
+    """Haar-uniform SO(3) matrices [B,3,3] from normalised Gaussian quaternions, generated on the device
+    (no host round trip: the reference's CPU rotation, shapenet_hyp_hc.py:63-69, is the step's only other host hop)."""
+    q = torch.randn(B, 4, device=device, generator=generator)
+    q = q / q.norm(dim=1, keepdim=True).clamp_min(1e-12)
+    w, x, y, z = q.unbind(1)
+    R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                     2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                     2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], dim=1)
+    return R.view(B, 3, 3)
 
 
 def to_categorical(y, num_classes):
@@ -32,7 +34,7 @@ def to_categorical(y, num_classes):
 class HypHCStep(torch.nn.Module):
     def __init__(self, nn_feat, nn_emb, hyp_size, num_class, num_categories=16, lr=1e-3, margin=0.5, t_per_anchor=50,
                  fraction=1.2, temperature=0.05, anneal_factor=0.5, trade_off=0.1, miner=True, cosface=True,
-                 train_rotation="so3", rng="device"):
+                 train_rotation="so3", rng="device", fused_filter=True):
         super().__init__()
         self.nn_feat = nn_feat
         self.nn_emb = nn_emb
@@ -43,7 +45,8 @@ class HypHCStep(torch.nn.Module):
         self.metric_hyp_loss = MetricHyperbolicLoss(margin=margin, t_per_anchor=t_per_anchor, fraction=fraction,
                                                     scale=self.scale, temperature=temperature,
                                                     anneal_factor=anneal_factor, num_class=num_class,
-                                                    embedding_size=hyp_size, miner=miner, cosface=cosface, rng=rng)
+                                                    embedding_size=hyp_size, miner=miner, cosface=cosface, rng=rng,
+                                                    fused_filter=fused_filter)
         self.lr = lr
         self.optimizer = None
         self.bucket = None

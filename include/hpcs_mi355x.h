@@ -181,15 +181,18 @@ size_t hpcs_triplet_filter_workspace(int64_t T);
 int hpcs_triplet_filter(const float* xn, int E, const int64_t* a, const int64_t* p, const int64_t* n, int64_t T,
                         float margin, int kind, int64_t* a_out, int64_t* p_out, int64_t* n_out, int64_t* count,
                         void* ws, size_t ws_bytes, hpcs_stream_t stream);
-/* hyphc: count (device int64, may be < T_cap) triplets.  fwd writes loss_sum[1] (double; sum over triplets of
- * sum(w) - sum(w*softmax(d/temp))).  bwd accumulates into gxn [M,E] (grad wrt unit rows, fp32 atomics) and
- * gscale[1] (double).  gloss is dL/d(mean term) / count applied by the kernel: upstream * 1/count. */
+/* hyphc: walks min(*count, T_cap) triplets.  kind < 0: every triplet counts (already mined).  kind >= 0
+ * (HPCS_TRIPLETS_*): the miner's margin rule is applied inline -- no compaction pass -- fwd writes the number of
+ * kept triplets to kept[1], and the mean is over those (pass it back as norm_count).  fwd writes loss_sum[1]
+ * (double; sum over kept triplets of sum(w) - sum(w*softmax(d/temp))).  bwd accumulates into gxn [M,E] (grad wrt
+ * unit rows; row-contiguous fp32 atomics) and writes gscale[1] (double); gloss = device scalar dL/d(mean term). */
 int hpcs_hyphc_fwd(const float* xn, int E, const int64_t* a, const int64_t* p, const int64_t* n,
-                   const int64_t* count, int64_t T_cap, const float* scale, float temperature, double* loss_sum,
-                   hpcs_stream_t stream);
+                   const int64_t* count, int64_t T_cap, const float* scale, float temperature, float margin,
+                   int kind, double* loss_sum, int64_t* kept, hpcs_stream_t stream);
 int hpcs_hyphc_bwd(const float* xn, int E, const int64_t* a, const int64_t* p, const int64_t* n,
-                   const int64_t* count, int64_t T_cap, const float* scale, float temperature,
-                   const float* gloss, float* gxn, double* gscale, hpcs_stream_t stream);
+                   const int64_t* count, int64_t T_cap, const float* scale, float temperature, float margin,
+                   int kind, const int64_t* norm_count, const float* gloss, float* gxn, double* gscale,
+                   hpcs_stream_t stream);
 /* mean of the M x M similarity in closed form: 0.5 + 0.5*|sum_i xn_i|^2/M^2.  colsum [E] double. */
 int hpcs_colsum(const float* xn, int64_t rows, int E, double* colsum, hpcs_stream_t stream);
 int hpcs_cosface_fwd(const float* xn, const float* wn, const int64_t* labels, int M, int E, int C, float margin,

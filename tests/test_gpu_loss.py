@@ -127,6 +127,27 @@ def test_hyphc_loss_and_grads(s):
     assert abs(wa.numel() - c) <= 8
 
 
+def test_fused_filter_equals_two_pass():
+    """Inline margin filter (no compaction) gives the same loss and gradients as filter-then-loss."""
+    from hpcs_amd.loss.ultrametric_loss import MetricHyperbolicLoss
+    M, E, C = 3000, 32, 5
+    x = OH.expmap0(det_normalish((M, E), 41) * 0.5)
+    lab = det_int((M,), 42, C)
+    res = []
+    for fused in (False, True):
+        scale = torch.nn.Parameter(torch.tensor([0.02]))
+        crit = MetricHyperbolicLoss(t_per_anchor=12, fraction=1.2, scale=scale, temperature=0.05, num_class=C,
+                                    embedding_size=E, cosface=True, miner=True, fused_filter=fused).to(dev)
+        xg = x.to(dev).requires_grad_(True)
+        torch.manual_seed(3)
+        lh = crit.compute_hyp(xg, lab.to(dev))
+        lh.backward()
+        res.append((float(lh), xg.grad.cpu(), float(crit.scale.grad)))
+    assert abs(res[0][0] - res[1][0]) <= 2e-6 * abs(res[0][0])
+    relclose(res[1][1], res[0][1], 1e-5)
+    assert abs(res[0][2] - res[1][2]) <= 1e-4 * abs(res[0][2])
+
+
 def test_triplet_branch_loss_and_grads():
     from hpcs_amd.loss.ultrametric_loss import MetricHyperbolicLoss
     M, E, C = 1200, 16, 4
