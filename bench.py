@@ -167,6 +167,8 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (hpcs_amd has no CPU fallback)")
+    if os.environ.get("HPCS_SINGLE_DEVICE_REHEARSAL"):      # several ranks sharing cuda:0 (gloo), code-path rehearsal only
+        local = 0
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
 
@@ -221,7 +223,8 @@ def main():
                    "global_batch": args.batch * world, "num_class": args.num_class,
                    "parallelism": f"dp{world} (per-replica BN and mining, one flat-gradient all-reduce)",
                    "triplet_rng": "device counter RNG (statistically equivalent to the reference's CPU torch.randint)",
-                   "metrics_in_step": "accuracy/IoU logging off", "final_total_loss": round(loss_val, 6)},
+                   "metrics_in_step": "accuracy/IoU logging off", "final_total_loss": round(loss_val, 6),
+                   "triplets_sampled_per_step_rank0": int(step.metric_hyp_loss.last_triplets[0].numel())},
     }
     if timed and prof:
         def dur(lst):

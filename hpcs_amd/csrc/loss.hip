@@ -133,10 +133,20 @@ __global__ void filter_flag_kernel(const float* __restrict__ xn, int E, const in
         const bool live = t < T;
         const int64_t ia = live ? a[t] : 0, ip = live ? p[t] : 0, in = live ? n[t] : 0;
         float dp = 0.f, dn = 0.f;
-        for (int e = s; e < E; e += SUB) {
-            const float av = xn[ia * E + e];
-            dp += av * xn[ip * E + e];
-            dn += av * xn[in * E + e];
+        if (E % SUB == 0) {          // same element->lane mapping and summation order as hyphc_kernel's FAST path
+            const int epl = E / SUB;
+            for (int j = 0; j < epl; ++j) {
+                const int e = s * epl + j;
+                const float av = xn[ia * E + e];
+                dp += av * xn[ip * E + e];
+                dn += av * xn[in * E + e];
+            }
+        } else {
+            for (int e = s; e < E; e += SUB) {
+                const float av = xn[ia * E + e];
+                dp += av * xn[ip * E + e];
+                dn += av * xn[in * E + e];
+            }
         }
         dp = sub_sum(dp);
         dn = sub_sum(dn);
@@ -243,9 +253,31 @@ __device__ __forceinline__ LcaF lca_of_dot(float s, float dot) {
 constexpr int RUN = 16;          // consecutive triplets walked by one 8-lane group (they mostly share the anchor)
 
 // EPL = ceil(E/8) elements per lane, rows live in registers.
-__device__ __forceinline__ int sub_lane0(int lane) { return lane & ~(SUB - 1); }
+// FAST: E == 8*EPL exactly (E = 16, 32, 64): lane s owns the EPL CONTIGUOUS elements [s*EPL, (s+1)*EPL) so a row is
+// gathered with one vector load per lane, and backward adds whole rows per atomic instruction via an LDS transpose.
+template <int EPL, bool FAST>
+struct RowIO {
+    static __device__ __forceinline__ int eidx(int s, int j) { return FAST ? s * EPL + j : s + SUB * j; }
+    static __device__ __forceinline__ void load(const float* __restrict__ xn, int E, int64_t row, int s, float (&v)[EPL]) {
+        if (FAST && EPL % 4 == 0) {
+#pragma unroll
+            for (int q = 0; q < EPL / 4; ++q) {
+                const float4 u = *reinterpret_cast<const float4*>(xn + row * E + s * EPL + 4 * q);
+                v[4 * q] = u.x; v[4 * q + 1] = u.y; v[4 * q + 2] = u.z; v[4 * q + 3] = u.w;
+            }
+        } else if (FAST && EPL == 2) {
+            const float2 u = *reinterpret_cast<const float2*>(xn + row * E + s * 2);
+            v[0] = u.x; v[1] = u.y;
+        } else {
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+                const int e = eidx(s, j);
+                v[j] = e < E ? xn[row * E + e] : 0.f;
+            }
+        }
+    }
+};
 
-// FAST: E == 8*EPL exactly (E = 16, 32, 64): row-contiguous atomics via an LDS transpose.
 template <int EPL, bool BWD, bool FAST>
 __global__ __launch_bounds__(TPB) void hyphc_kernel(const float* __restrict__ xn, int E, const int64_t* __restrict__ a,
                                                     const int64_t* __restrict__ p, const int64_t* __restrict__ n,
@@ -255,8 +287,11 @@ __global__ __launch_bounds__(TPB) void hyphc_kernel(const float* __restrict__ xn
                                                     unsigned long long* __restrict__ kept_out,
                                                     const float* __restrict__ gloss, double* __restrict__ loss_sum,
                                                     float* __restrict__ gxn, double* __restrict__ gscale, unsigned perm_mul) {
+    using IO = RowIO<EPL, FAST>;
+    static_assert(RUN == 2 * SUB, "index prefetch assumes two index slots per lane");
     __shared__ double red[16];
-    __shared__ float stage[(BWD && FAST) ? (TPB / 64) * 2 * 8 * (8 * EPL + 8) : 1];
+    constexpr int LD = 8 * EPL + 8;
+    __shared__ __attribute__((aligned(16))) float stage[(BWD && FAST) ? (TPB / 64) * 2 * 8 * LD : 4];
     const int64_t T = *count < T_cap ? *count : T_cap;
     const float sraw = *scale;
     const float sc = fminf(fmaxf(sraw, 1e-4f), 1.f);
@@ -277,25 +312,41 @@ __global__ __launch_bounds__(TPB) void hyphc_kernel(const float* __restrict__ xn
     const unsigned pblock = (unsigned)(((uint64_t)blockIdx.x * perm_mul) % gridDim.x);
     const int64_t base = ((int64_t)pblock * TRIP_PER_PASS + g) * RUN;
 
+    // the group's RUN triplet indices, fetched once (coalesced): lane s holds entries s and s+8
+    int64_t ta[2], tp[2], tn[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int64_t t = base + s + SUB * h;
+        const bool ok = t < T;
+        ta[h] = ok ? a[t] : 0;
+        tp[h] = ok ? p[t] : 0;
+        tn[h] = ok ? n[t] : 0;
+    }
+    auto fetch = [&](int i, int64_t& ia, int64_t& ip, int64_t& in, float (&av)[EPL], float (&pv)[EPL], float (&nv)[EPL]) {
+        const int src = sub0 + (i & (SUB - 1));
+        ia = __shfl(i < SUB ? ta[0] : ta[1], src, 64);
+        ip = __shfl(i < SUB ? tp[0] : tp[1], src, 64);
+        in = __shfl(i < SUB ? tn[0] : tn[1], src, 64);
+        IO::load(xn, E, ia, s, av);
+        IO::load(xn, E, ip, s, pv);
+        IO::load(xn, E, in, s, nv);
+    };
+
     double acc = 0.0;
     float acc_a[EPL];
     int64_t cur = -1;
 #pragma unroll
     for (int j = 0; j < EPL; ++j) acc_a[j] = 0.f;
 
+    int64_t ia, ip, in, ia2 = 0, ip2 = 0, in2 = 0;
+    float av[EPL], pv[EPL], nv[EPL], av2[EPL], pv2[EPL], nv2[EPL];
+    fetch(0, ia, ip, in, av, pv, nv);
     for (int i = 0; i < RUN; ++i) {
-        const int64_t t = base + i;
-        bool live = t < T;
-        const int64_t ia = live ? a[t] : 0, ip = live ? p[t] : 0, in = live ? n[t] : 0;
-        float av[EPL], pv[EPL], nv[EPL];
+        if (i + 1 < RUN) fetch(i + 1, ia2, ip2, in2, av2, pv2, nv2);      // next triplet's rows are in flight during the math
+        bool live = base + i < T;
         float d1 = 0.f, d2 = 0.f, d3 = 0.f;
 #pragma unroll
         for (int j = 0; j < EPL; ++j) {
-            const int e = s + SUB * j;
-            const bool ok = e < E;
-            av[j] = ok ? xn[ia * E + e] : 0.f;
-            pv[j] = ok ? xn[ip * E + e] : 0.f;
-            nv[j] = ok ? xn[in * E + e] : 0.f;
             d1 += av[j] * pv[j];
             d2 += av[j] * nv[j];
             d3 += pv[j] * nv[j];
@@ -334,33 +385,31 @@ __global__ __launch_bounds__(TPB) void hyphc_kernel(const float* __restrict__ xn
                     if (cur >= 0) {
 #pragma unroll
                         for (int j = 0; j < EPL; ++j)
-                            if (s + SUB * j < E) atomicAdd(gxn + cur * E + s + SUB * j, acc_a[j]);
+                            if (IO::eidx(s, j) < E) atomicAdd(gxn + cur * E + IO::eidx(s, j), acc_a[j]);
                     }
                     cur = ia;
 #pragma unroll
                     for (int j = 0; j < EPL; ++j) acc_a[j] = 0.f;
                 }
 #pragma unroll
-                for (int j = 0; j < EPL; ++j)
-                    if (s + SUB * j < E) acc_a[j] += c0 * pv[j] + c1 * nv[j];
+                for (int j = 0; j < EPL; ++j) acc_a[j] += c0 * pv[j] + c1 * nv[j];
             }
             if (FAST) {
                 // positive / negative rows are random: give every atomic wave-instruction whole contiguous rows
                 // (64/E rows x E floats = 256 B) by transposing the 8 triplets' updates through a wave-private LDS
                 // slab -- the full-rate shape of MI355X_MICROARCH "Global float atomics".
-                float* slab = stage + (threadIdx.x >> 6) * (2 * 8 * (8 * EPL + 8));
-                constexpr int LD = 8 * EPL + 8;
+                float* slab = stage + (threadIdx.x >> 6) * (2 * 8 * LD);
                 const int gi = (lane >> 3);
 #pragma unroll
                 for (int j = 0; j < EPL; ++j) {
-                    slab[gi * LD + s + SUB * j] = live ? c0 * av[j] + c2 * nv[j] : 0.f;
-                    slab[8 * LD + gi * LD + s + SUB * j] = live ? c1 * av[j] + c2 * pv[j] : 0.f;
+                    slab[gi * LD + s * EPL + j] = live ? c0 * av[j] + c2 * nv[j] : 0.f;
+                    slab[8 * LD + gi * LD + s * EPL + j] = live ? c1 * av[j] + c2 * pv[j] : 0.f;
                 }
                 __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): the slab is wave-private, no barrier needed
                 constexpr int RPI = 64 / (8 * EPL);          // rows per instruction
 #pragma unroll
-                for (int i = 0; i < EPL; ++i) {
-                    const int tl = i * RPI + lane / (8 * EPL), e = lane % (8 * EPL);
+                for (int r = 0; r < EPL; ++r) {
+                    const int tl = r * RPI + lane / (8 * EPL), e = lane % (8 * EPL);
                     const int64_t rp = __shfl(ip, tl * SUB, 64);
                     const int64_t rn = __shfl(in, tl * SUB, 64);
                     const bool lv = __shfl((int)live, tl * SUB, 64) != 0;
@@ -372,7 +421,7 @@ __global__ __launch_bounds__(TPB) void hyphc_kernel(const float* __restrict__ xn
             } else if (live) {
 #pragma unroll
                 for (int j = 0; j < EPL; ++j) {
-                    const int e = s + SUB * j;
+                    const int e = IO::eidx(s, j);
                     if (e < E) {
                         atomicAdd(gxn + ip * E + e, c0 * av[j] + c2 * nv[j]);
                         atomicAdd(gxn + in * E + e, c1 * av[j] + c2 * pv[j]);
@@ -380,11 +429,14 @@ __global__ __launch_bounds__(TPB) void hyphc_kernel(const float* __restrict__ xn
                 }
             }
         }
+        ia = ia2; ip = ip2; in = in2;
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) { av[j] = av2[j]; pv[j] = pv2[j]; nv[j] = nv2[j]; }
     }
     if (BWD && cur >= 0) {
 #pragma unroll
         for (int j = 0; j < EPL; ++j)
-            if (s + SUB * j < E) atomicAdd(gxn + cur * E + s + SUB * j, acc_a[j]);
+            if (IO::eidx(s, j) < E) atomicAdd(gxn + cur * E + IO::eidx(s, j), acc_a[j]);
     }
     const double tot = hpcs_block_sum<double>(acc, red);
     if (threadIdx.x == 0 && tot != 0.0) atomicAdd(BWD ? gscale : loss_sum, tot);
@@ -409,7 +461,7 @@ int launch_hyphc(const float* xn, int E, const int64_t* a, const int64_t* p, con
     }
 #define HPCS_HYPHC_CASE(EPL)                                                                                          \
     if (E <= 8 * EPL) {                                                                                               \
-        if (BWD && E == 8 * EPL && EPL >= 2)                                                                          \
+        if (E == 8 * EPL && EPL >= 2)                                                                                 \
             hipLaunchKernelGGL((hyphc_kernel<EPL, BWD, true>), grid, dim3(TPB), 0, st, xn, E, a, p, n, count, T_cap, \
                                scale, temperature, margin, kind, norm_count, kept_out, gloss, loss_sum, gxn, gscale, perm_mul); \
         else                                                                                                          \

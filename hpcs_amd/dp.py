@@ -59,7 +59,8 @@ def init_distributed(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"     # "nccl" is RCCL on ROCm
+            backend = os.environ.get("HPCS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+            # "nccl" is RCCL on ROCm; HPCS_DIST_BACKEND=gloo rehearses the multi-rank path on one GPU
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
