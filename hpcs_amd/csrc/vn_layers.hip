@@ -69,7 +69,7 @@ __global__ void edge_gather_bwd_center_kernel(const float* __restrict__ gout, in
 // "Global float atomics").  A second pass folds tmp into gx.
 constexpr int ET = 64;
 __global__ __launch_bounds__(256) void edge_scatter_tile_kernel(const float* __restrict__ gout, const int64_t* __restrict__ idx,
-                                                                int C, int N, int k, int CP, float* __restrict__ tmp) {
+                                                                int C, int Csrc, int N, int k, int CP, float* __restrict__ tmp) {
     extern __shared__ float tile[];            // [ET][C3+1]
     const int C3 = C * 3;
     const int ld = C3 | 1;                     // odd row pitch: the transposing LDS writes hit 32 distinct banks
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void edge_scatter_tile_kernel(const float* __r
     const bool lok = l0 + lane < L;
     for (int ca = w; ca < C3; ca += 4) {
         const int c = ca / 3, a = ca % 3;
-        tile[lane * ld + ca] = lok ? gout[(((int64_t)b * 2 * C + c) * 3 + a) * L + l0 + lane] : 0.f;
+        tile[lane * ld + ca] = lok ? gout[(((int64_t)b * Csrc + c) * 3 + a) * L + l0 + lane] : 0.f;
     }
     __syncthreads();
     for (int e = w; e < ET; e += 4) {
@@ -91,12 +91,40 @@ __global__ __launch_bounds__(256) void edge_scatter_tile_kernel(const float* __r
     }
 }
 
-__global__ void edge_scatter_fold_kernel(const float* __restrict__ tmp, int C, int N, int CP, float* __restrict__ gx) {
+// accumulate != 0: gx += tmp (gx already holds the centre part); 0: gx = tmp.  Cdst = channels per cloud of gx.
+__global__ void edge_scatter_fold_kernel(const float* __restrict__ tmp, int C, int Cdst, int N, int CP, int accumulate,
+                                         float* __restrict__ gx) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     const int b = blockIdx.y;
     const float* row = tmp + ((int64_t)b * N + n) * CP;
-    for (int ca = 0; ca < C * 3; ++ca) gx[((int64_t)b * C * 3 + ca) * N + n] += row[ca];
+    for (int ca = 0; ca < C * 3; ++ca) {
+        float* d = gx + ((int64_t)b * Cdst * 3 + ca) * N + n;
+        *d = accumulate ? *d + row[ca] : row[ca];
+    }
+}
+
+// gV[b,c,a,n] = sum_j GPD[b,c,a,n*k+j]  (segment sum over the k neighbours; written into channels [Ctot,2Ctot) of gUV)
+template <bool VEC>
+__global__ void edge_segsum_kernel(const float* __restrict__ GPD, int Ctot, int N, int k, float* __restrict__ gUV) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int c = blockIdx.y, b = blockIdx.z;
+    const int64_t L = (int64_t)N * k;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float* g = GPD + (((int64_t)b * Ctot + c) * 3 + a) * L + (int64_t)n * k;
+        float s = 0.f;
+        if (VEC) {
+            for (int j = 0; j < k; j += 4) {
+                const float4 u = *reinterpret_cast<const float4*>(g + j);
+                s += (u.x + u.y) + (u.z + u.w);
+            }
+        } else {
+            for (int j = 0; j < k; ++j) s += g[j];
+        }
+        gUV[(((int64_t)b * 2 * Ctot + Ctot + c) * 3 + a) * N + n] = s;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ a3
@@ -166,7 +194,35 @@ __device__ __forceinline__ void load3(const float* __restrict__ base, int64_t L,
     v[2] = base[2 * L];
 }
 
-__global__ void vn_norm_stats_kernel(const float* __restrict__ PD, int B, int Ctot, int64_t L, int Cout,
+// Where a VN layer's pre-activations (p, d) come from.
+//   idx == nullptr : base = PD [B, Ctot, 3, L], materialised by the channel GEMM.
+//   idx != nullptr : EdgeConv "gather" layer.  Its input is the edge feature (x[nbr]-x[ctr], x[ctr]), so
+//                    W [x_nbr - x_ctr ; x_ctr] = W_a x_nbr + (W_b - W_a) x_ctr: base = UV [B, 2*Ctot, 3, N] holds the
+//                    POINT-level products U = W_a F, V = (W_b - W_a) F (a GEMM k times smaller than the edge GEMM) and
+//                    PD[b,ch,:,n*k+j] = U[b,ch,:,idx[b,n,j]] + V[b,ch,:,n] is formed on the fly; neither the
+//                    [B,2C,3,N,k] edge tensor (vn_dgcnn_util.py:33-39) nor PD ever reaches HBM.
+struct PdRef {
+    const float* base;
+    const int64_t* idx;
+    int Ctot;
+    int64_t L;
+    int N, k;
+};
+
+__device__ __forceinline__ void pd_load3(const PdRef& r, int64_t b, int ch, int64_t l, float (&v)[3]) {
+    if (r.idx == nullptr) {
+        load3(r.base + ((b * r.Ctot + ch) * 3) * r.L + l, r.L, v);
+        return;
+    }
+    const int64_t j = r.idx[b * r.L + l];
+    const int64_t n = l / r.k;
+    const float* U = r.base + ((b * 2 * r.Ctot + ch) * 3) * r.N;
+    const float* V = r.base + ((b * 2 * r.Ctot + r.Ctot + ch) * 3) * r.N;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) v[a] = U[(int64_t)a * r.N + j] + V[(int64_t)a * r.N + n];
+}
+
+__global__ void vn_norm_stats_kernel(PdRef pd, int B, int Ctot, int64_t L, int Cout,
                                      double* __restrict__ sums) {
     __shared__ double red[16];
     const int c = blockIdx.y;
@@ -179,7 +235,7 @@ __global__ void vn_norm_stats_kernel(const float* __restrict__ PD, int B, int Ct
         if (e < total) {
             const int64_t b = e / L, l = e % L;
             float p[3];
-            load3(PD + ((b * Ctot + c) * 3) * L + l, L, p);
+            pd_load3(pd, b, c, l, p);
             const float n = sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]) + VN_EPS;
             s1 += n;
             s2 += n * n;
@@ -215,7 +271,7 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, int C, doubl
     }
 }
 
-__global__ void vn_apply_fwd_kernel(const float* __restrict__ PD, const float* __restrict__ mean,
+__global__ void vn_apply_fwd_kernel(PdRef pd, const float* __restrict__ mean,
                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
                                     const float* __restrict__ beta, int B, int Cout, int Cd, int64_t L, float slope,
                                     int flags, float* __restrict__ out) {
@@ -226,8 +282,8 @@ __global__ void vn_apply_fwd_kernel(const float* __restrict__ PD, const float* _
     if (e >= (int64_t)B * L) return;
     const int64_t b = e / L, l = e % L;
     VnPoint s;
-    load3(PD + ((b * Ctot + c) * 3) * L + l, L, s.p);
-    if (flags & HPCS_VN_LRELU) load3(PD + ((b * Ctot + cd) * 3) * L + l, L, s.d);
+    pd_load3(pd, b, c, l, s.p);
+    if (flags & HPCS_VN_LRELU) pd_load3(pd, b, cd, l, s.d);
     else s.d[0] = s.d[1] = s.d[2] = 0.f;
     const bool bn = flags & HPCS_VN_BN;
     vn_forward_point(s, bn ? mean[c] : 0.f, bn ? rstd[c] : 1.f, bn ? gamma[c] : 1.f, bn ? beta[c] : 0.f, flags);
@@ -242,7 +298,7 @@ __global__ void vn_apply_fwd_kernel(const float* __restrict__ PD, const float* _
 // fused mean_pool over groups of pool_k consecutive l: one thread per (b, n).  Each thread owns pool_k contiguous
 // floats per plane, so a wave covers one contiguous span; float4 loads when pool_k % 4 == 0.
 template <bool VEC>
-__global__ void vn_apply_pool_fwd_kernel(const float* __restrict__ PD, const float* __restrict__ mean,
+__global__ void vn_apply_pool_fwd_kernel(PdRef pd, const float* __restrict__ mean,
                                          const float* __restrict__ rstd, const float* __restrict__ gamma,
                                          const float* __restrict__ beta, int B, int Cout, int Cd, int64_t L, int pool_k,
                                          float slope, int flags, float* __restrict__ out) {
@@ -256,7 +312,8 @@ __global__ void vn_apply_pool_fwd_kernel(const float* __restrict__ PD, const flo
     const bool bn = flags & HPCS_VN_BN;
     const bool act = flags & HPCS_VN_LRELU;
     const float mu = bn ? mean[c] : 0.f, rs = bn ? rstd[c] : 1.f, ga = bn ? gamma[c] : 1.f, be = bn ? beta[c] : 0.f;
-    const float* pp = PD + ((b * Ctot + c) * 3) * L + n * pool_k;
+    const float* PD = pd.base;
+    const float* pp = PD + ((b * Ctot + c) * 3) * L + n * pool_k;       // only dereferenced in the materialised mode
     const float* dp = PD + ((b * Ctot + cd) * 3) * L + n * pool_k;
     float acc[3] = {0.f, 0.f, 0.f};
     constexpr int W = VEC ? 4 : 1;
@@ -271,9 +328,18 @@ __global__ void vn_apply_pool_fwd_kernel(const float* __restrict__ PD, const flo
                     const float4 v = *reinterpret_cast<const float4*>(dp + a * L + j);
                     dv[a][0] = v.x; dv[a][1] = v.y; dv[a][2] = v.z; dv[a][3] = v.w;
                 }
-            } else {
+            } else if (pd.idx == nullptr) {
                 pv[a][0] = pp[a * L + j];
                 if (act) dv[a][0] = dp[a * L + j];
+            }
+        }
+        if (!VEC && pd.idx != nullptr) {
+            float t3[3];
+            pd_load3(pd, b, c, n * pool_k + j, t3);
+            pv[0][0] = t3[0]; pv[1][0] = t3[1]; pv[2][0] = t3[2];
+            if (act) {
+                pd_load3(pd, b, cd, n * pool_k + j, t3);
+                dv[0][0] = t3[0]; dv[1][0] = t3[1]; dv[2][0] = t3[2];
             }
         }
 #pragma unroll
@@ -313,7 +379,7 @@ __device__ __forceinline__ void load_gout(const float* __restrict__ gout, int64_
     }
 }
 
-__global__ void vn_bwd_reduce_kernel(const float* __restrict__ PD, const float* __restrict__ gout,
+__global__ void vn_bwd_reduce_kernel(PdRef pd, const float* __restrict__ gout,
                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                      const float* __restrict__ gamma, const float* __restrict__ beta, int B, int Cout,
                                      int Cd, int64_t L, int pool_k, float slope, int flags, double* __restrict__ red_out) {
@@ -331,8 +397,8 @@ __global__ void vn_bwd_reduce_kernel(const float* __restrict__ PD, const float* 
         if (e < total) {
             const int64_t b = e / L, l = e % L;
             VnPoint s;
-            load3(PD + ((b * Ctot + c) * 3) * L + l, L, s.p);
-            if (flags & HPCS_VN_LRELU) load3(PD + ((b * Ctot + cd) * 3) * L + l, L, s.d);
+            pd_load3(pd, b, c, l, s.p);
+            if (flags & HPCS_VN_LRELU) pd_load3(pd, b, cd, l, s.d);
             else s.d[0] = s.d[1] = s.d[2] = 0.f;
             vn_forward_point(s, mu, rs, ga, be, flags);
             float g[3], gq[3], gd[3];
@@ -352,7 +418,7 @@ __global__ void vn_bwd_reduce_kernel(const float* __restrict__ PD, const float* 
 }
 
 template <bool SHARED>
-__global__ void vn_bwd_apply_kernel(const float* __restrict__ PD, const float* __restrict__ gout,
+__global__ void vn_bwd_apply_kernel(PdRef pd, const float* __restrict__ gout,
                                     const float* __restrict__ mean, const float* __restrict__ rstd,
                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                     const double* __restrict__ red, int training, int B, int Cout, int Cd, int64_t L,
@@ -367,14 +433,14 @@ __global__ void vn_bwd_apply_kernel(const float* __restrict__ PD, const float* _
     const bool bn = flags & HPCS_VN_BN;
     float gdsum[3] = {0.f, 0.f, 0.f};
     float dsh[3] = {0.f, 0.f, 0.f};
-    if (SHARED && (flags & HPCS_VN_LRELU)) load3(PD + ((b * Ctot + Cout) * 3) * L + l, L, dsh);
+    if (SHARED && (flags & HPCS_VN_LRELU)) pd_load3(pd, b, Cout, l, dsh);
     for (int c = c_begin; c < c_end; ++c) {
         VnPoint s;
-        load3(PD + ((b * Ctot + c) * 3) * L + l, L, s.p);
+        pd_load3(pd, b, c, l, s.p);
         if (SHARED) {
             s.d[0] = dsh[0]; s.d[1] = dsh[1]; s.d[2] = dsh[2];
         } else if (flags & HPCS_VN_LRELU) {
-            load3(PD + ((b * Ctot + Cout + c) * 3) * L + l, L, s.d);
+            pd_load3(pd, b, Cout + c, l, s.d);
         } else {
             s.d[0] = s.d[1] = s.d[2] = 0.f;
         }
@@ -734,9 +800,18 @@ extern "C" int hpcs_edge_gather_bwd(const float* gout, const int64_t* idx, int B
     if (hipMemsetAsync(ws, 0, (size_t)B * N * CP * sizeof(float), ST) != hipSuccess) return HPCS_ERR_HIP;
     const size_t lds = (size_t)ET * (C * 3 + 1) * sizeof(float);
     if (lds > 64 * 1024) return HPCS_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(edge_scatter_tile_kernel, dim3(hpcs_cdiv(L, ET), B), dim3(256), lds, ST, gout, idx, C, N, k, CP, (float*)ws);
+    hipLaunchKernelGGL(edge_scatter_tile_kernel, dim3(hpcs_cdiv(L, ET), B), dim3(256), lds, ST, gout, idx, C, 2 * C, N, k, CP, (float*)ws);
     HPCS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(edge_scatter_fold_kernel, dim3(hpcs_cdiv(N, 64), B), dim3(64), 0, ST, (const float*)ws, C, N, CP, gx);
+    hipLaunchKernelGGL(edge_scatter_fold_kernel, dim3(hpcs_cdiv(N, 64), B), dim3(64), 0, ST, (const float*)ws, C, C, N, CP, 1, gx);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
+static int vn_norm_stats_impl(PdRef pd, int B, int Cout, double* sums, hipStream_t st) {
+    if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * Cout, st) != hipSuccess) return HPCS_ERR_HIP;
+    if (B == 0) return HPCS_OK;
+    hipLaunchKernelGGL(vn_norm_stats_kernel, dim3(hpcs_cdiv((int64_t)B * pd.L, TPB * ITEMS), Cout), dim3(TPB), 0, st, pd, B,
+                       pd.Ctot, pd.L, Cout, sums);
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;
 }
@@ -744,12 +819,14 @@ extern "C" int hpcs_edge_gather_bwd(const float* gout, const int64_t* idx, int B
 extern "C" int hpcs_vn_norm_stats(const float* PD, int B, int Cout, int Ctot, int64_t L, double* sums, hpcs_stream_t stream) {
     if (!PD || !sums) return HPCS_ERR_NULL;
     if (bad_dims(B, Cout, L) || Ctot < Cout || Cout > 65535) return HPCS_ERR_SHAPE;
-    if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * Cout, ST) != hipSuccess) return HPCS_ERR_HIP;
-    if (B == 0) return HPCS_OK;
-    hipLaunchKernelGGL(vn_norm_stats_kernel, dim3(hpcs_cdiv((int64_t)B * L, TPB * ITEMS), Cout), dim3(TPB), 0, ST, PD, B,
-                       Ctot, L, Cout, sums);
-    HPCS_CHECK_LAUNCH();
-    return HPCS_OK;
+    return vn_norm_stats_impl(PdRef{PD, nullptr, Ctot, L, 0, 0}, B, Cout, sums, ST);
+}
+
+extern "C" int hpcs_vn_edge_norm_stats(const float* UV, const int64_t* idx, int B, int Cout, int Ctot, int N, int k,
+                                       double* sums, hpcs_stream_t stream) {
+    if (!UV || !idx || !sums) return HPCS_ERR_NULL;
+    if (B < 0 || Cout <= 0 || N <= 0 || k <= 0 || Ctot < Cout || Cout > 65535) return HPCS_ERR_SHAPE;
+    return vn_norm_stats_impl(PdRef{UV, idx, Ctot, (int64_t)N * k, N, k}, B, Cout, sums, ST);
 }
 
 extern "C" int hpcs_bn_finalize(const double* sums, int C, int64_t count, float eps, float momentum, float* running_mean,
@@ -772,6 +849,53 @@ static int vn_args_ok(const void* PD, const void* mean, const void* rstd, const 
     return HPCS_OK;
 }
 
+static int vn_apply_fwd_impl(PdRef pd, const float* mean, const float* rstd, const float* gamma, const float* beta, int B,
+                             int Cout, int Cd, int pool_k, float slope, int flags, float* out, hipStream_t st) {
+    const int64_t L = pd.L;
+    if (pool_k > 0) {
+        const bool vec = pd.idx == nullptr && (pool_k % 4 == 0) && (L % 4 == 0) && (((uintptr_t)pd.base & 15u) == 0);
+        const dim3 grid(hpcs_cdiv((int64_t)B * (L / pool_k), 64), Cout);
+        if (vec)
+            hipLaunchKernelGGL((vn_apply_pool_fwd_kernel<true>), grid, dim3(64), 0, st, pd, mean, rstd, gamma, beta, B, Cout,
+                               Cd, L, pool_k, slope, flags, out);
+        else
+            hipLaunchKernelGGL((vn_apply_pool_fwd_kernel<false>), grid, dim3(64), 0, st, pd, mean, rstd, gamma, beta, B, Cout,
+                               Cd, L, pool_k, slope, flags, out);
+    } else {
+        hipLaunchKernelGGL(vn_apply_fwd_kernel, dim3(hpcs_cdiv((int64_t)B * L, TPB), Cout), dim3(TPB), 0, st, pd, mean,
+                           rstd, gamma, beta, B, Cout, Cd, L, slope, flags, out);
+    }
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
+static int vn_bwd_reduce_impl(PdRef pd, const float* gout, const float* mean, const float* rstd, const float* gamma,
+                              const float* beta, int B, int Cout, int Cd, int pool_k, float slope, int flags, double* red,
+                              hipStream_t st) {
+    if (!(flags & HPCS_VN_BN)) return HPCS_ERR_UNSUPPORTED;
+    if (hipMemsetAsync(red, 0, sizeof(double) * 2 * Cout, st) != hipSuccess) return HPCS_ERR_HIP;
+    if (B == 0) return HPCS_OK;
+    hipLaunchKernelGGL(vn_bwd_reduce_kernel, dim3(hpcs_cdiv((int64_t)B * pd.L, TPB * ITEMS), Cout), dim3(TPB), 0, st, pd, gout,
+                       mean, rstd, gamma, beta, B, Cout, Cd, pd.L, pool_k, slope, flags, red);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
+static int vn_bwd_apply_impl(PdRef pd, const float* gout, const float* mean, const float* rstd, const float* gamma,
+                             const float* beta, const double* red, int training, int B, int Cout, int Cd, int pool_k,
+                             float slope, int flags, float* GPD, hipStream_t st) {
+    if (B == 0) return HPCS_OK;
+    const int64_t L = pd.L;
+    if (Cd == 1 && (flags & HPCS_VN_LRELU))
+        hipLaunchKernelGGL((vn_bwd_apply_kernel<true>), dim3(hpcs_cdiv((int64_t)B * L, TPB), 1), dim3(TPB), 0, st, pd, gout,
+                           mean, rstd, gamma, beta, red, training, B, Cout, Cd, L, pool_k, slope, flags, GPD);
+    else
+        hipLaunchKernelGGL((vn_bwd_apply_kernel<false>), dim3(hpcs_cdiv((int64_t)B * L, TPB), Cout), dim3(TPB), 0, st, pd,
+                           gout, mean, rstd, gamma, beta, red, training, B, Cout, Cd, L, pool_k, slope, flags, GPD);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
 extern "C" int hpcs_vn_apply_fwd(const float* PD, const float* mean, const float* rstd, const float* gamma,
                                  const float* beta, int B, int Cout, int Cd, int64_t L, int pool_k, float slope, int flags,
                                  float* out, hpcs_stream_t stream) {
@@ -779,20 +903,8 @@ extern "C" int hpcs_vn_apply_fwd(const float* PD, const float* mean, const float
     if (rc) return rc;
     if (!out) return HPCS_ERR_NULL;
     if (B == 0) return HPCS_OK;
-    if (pool_k > 0) {
-        const bool vec = (pool_k % 4 == 0) && (L % 4 == 0) && (((uintptr_t)PD & 15u) == 0);
-        const dim3 grid(hpcs_cdiv((int64_t)B * (L / pool_k), 64), Cout);
-        if (vec)
-            hipLaunchKernelGGL((vn_apply_pool_fwd_kernel<true>), grid, dim3(64), 0, ST, PD, mean, rstd, gamma, beta, B, Cout,
-                               Cd, L, pool_k, slope, flags, out);
-        else
-            hipLaunchKernelGGL((vn_apply_pool_fwd_kernel<false>), grid, dim3(64), 0, ST, PD, mean, rstd, gamma, beta, B, Cout,
-                               Cd, L, pool_k, slope, flags, out);
-    } else
-        hipLaunchKernelGGL(vn_apply_fwd_kernel, dim3(hpcs_cdiv((int64_t)B * L, TPB), Cout), dim3(TPB), 0, ST, PD, mean,
-                           rstd, gamma, beta, B, Cout, Cd, L, slope, flags, out);
-    HPCS_CHECK_LAUNCH();
-    return HPCS_OK;
+    return vn_apply_fwd_impl(PdRef{PD, nullptr, Cout + Cd, L, 0, 0}, mean, rstd, gamma, beta, B, Cout, Cd, pool_k, slope,
+                             flags, out, ST);
 }
 
 extern "C" int hpcs_vn_bwd_reduce(const float* PD, const float* gout, const float* mean, const float* rstd,
@@ -801,13 +913,8 @@ extern "C" int hpcs_vn_bwd_reduce(const float* PD, const float* gout, const floa
     int rc = vn_args_ok(PD, mean, rstd, gamma, beta, B, Cout, Cd, L, pool_k, flags);
     if (rc) return rc;
     if (!gout || !red) return HPCS_ERR_NULL;
-    if (!(flags & HPCS_VN_BN)) return HPCS_ERR_UNSUPPORTED;
-    if (hipMemsetAsync(red, 0, sizeof(double) * 2 * Cout, ST) != hipSuccess) return HPCS_ERR_HIP;
-    if (B == 0) return HPCS_OK;
-    hipLaunchKernelGGL(vn_bwd_reduce_kernel, dim3(hpcs_cdiv((int64_t)B * L, TPB * ITEMS), Cout), dim3(TPB), 0, ST, PD, gout,
-                       mean, rstd, gamma, beta, B, Cout, Cd, L, pool_k, slope, flags, red);
-    HPCS_CHECK_LAUNCH();
-    return HPCS_OK;
+    return vn_bwd_reduce_impl(PdRef{PD, nullptr, Cout + Cd, L, 0, 0}, gout, mean, rstd, gamma, beta, B, Cout, Cd, pool_k,
+                              slope, flags, red, ST);
 }
 
 extern "C" int hpcs_vn_bwd_apply(const float* PD, const float* gout, const float* mean, const float* rstd,
@@ -817,13 +924,85 @@ extern "C" int hpcs_vn_bwd_apply(const float* PD, const float* gout, const float
     if (rc) return rc;
     if (!gout || !GPD) return HPCS_ERR_NULL;
     if ((flags & HPCS_VN_BN) && training && !red) return HPCS_ERR_NULL;
+    return vn_bwd_apply_impl(PdRef{PD, nullptr, Cout + Cd, L, 0, 0}, gout, mean, rstd, gamma, beta, red, training, B, Cout,
+                             Cd, pool_k, slope, flags, GPD, ST);
+}
+
+// ---- EdgeConv gather layers: same kernels, pre-activations formed from the point-level products UV -------------
+static int edge_args_ok(const void* UV, const void* idx, int B, int N, int k) {
+    if (!UV || !idx) return HPCS_ERR_NULL;
+    if (B < 0 || N <= 0 || k <= 0) return HPCS_ERR_SHAPE;
+    return HPCS_OK;
+}
+
+extern "C" int hpcs_vn_edge_apply_fwd(const float* UV, const int64_t* idx, const float* mean, const float* rstd,
+                                      const float* gamma, const float* beta, int B, int Cout, int Cd, int N, int k,
+                                      int pool, float slope, int flags, float* out, hpcs_stream_t stream) {
+    int rc = edge_args_ok(UV, idx, B, N, k);
+    if (rc) return rc;
+    rc = vn_args_ok(UV, mean, rstd, gamma, beta, B, Cout, Cd, (int64_t)N * k, pool ? k : 0, flags);
+    if (rc) return rc;
+    if (!out) return HPCS_ERR_NULL;
     if (B == 0) return HPCS_OK;
-    if (Cd == 1 && (flags & HPCS_VN_LRELU))
-        hipLaunchKernelGGL((vn_bwd_apply_kernel<true>), dim3(hpcs_cdiv((int64_t)B * L, TPB), 1), dim3(TPB), 0, ST, PD, gout,
-                           mean, rstd, gamma, beta, red, training, B, Cout, Cd, L, pool_k, slope, flags, GPD);
+    return vn_apply_fwd_impl(PdRef{UV, idx, Cout + Cd, (int64_t)N * k, N, k}, mean, rstd, gamma, beta, B, Cout, Cd,
+                             pool ? k : 0, slope, flags, out, ST);
+}
+
+extern "C" int hpcs_vn_edge_bwd_reduce(const float* UV, const int64_t* idx, const float* gout, const float* mean,
+                                       const float* rstd, const float* gamma, const float* beta, int B, int Cout, int Cd,
+                                       int N, int k, int pool, float slope, int flags, double* red, hpcs_stream_t stream) {
+    int rc = edge_args_ok(UV, idx, B, N, k);
+    if (rc) return rc;
+    rc = vn_args_ok(UV, mean, rstd, gamma, beta, B, Cout, Cd, (int64_t)N * k, pool ? k : 0, flags);
+    if (rc) return rc;
+    if (!gout || !red) return HPCS_ERR_NULL;
+    return vn_bwd_reduce_impl(PdRef{UV, idx, Cout + Cd, (int64_t)N * k, N, k}, gout, mean, rstd, gamma, beta, B, Cout, Cd,
+                              pool ? k : 0, slope, flags, red, ST);
+}
+
+extern "C" int hpcs_vn_edge_bwd_apply(const float* UV, const int64_t* idx, const float* gout, const float* mean,
+                                      const float* rstd, const float* gamma, const float* beta, const double* red,
+                                      int training, int B, int Cout, int Cd, int N, int k, int pool, float slope, int flags,
+                                      float* GPD, hpcs_stream_t stream) {
+    int rc = edge_args_ok(UV, idx, B, N, k);
+    if (rc) return rc;
+    rc = vn_args_ok(UV, mean, rstd, gamma, beta, B, Cout, Cd, (int64_t)N * k, pool ? k : 0, flags);
+    if (rc) return rc;
+    if (!gout || !GPD) return HPCS_ERR_NULL;
+    if ((flags & HPCS_VN_BN) && training && !red) return HPCS_ERR_NULL;
+    return vn_bwd_apply_impl(PdRef{UV, idx, Cout + Cd, (int64_t)N * k, N, k}, gout, mean, rstd, gamma, beta, red, training,
+                             B, Cout, Cd, pool ? k : 0, slope, flags, GPD, ST);
+}
+
+extern "C" size_t hpcs_edge_grad_reduce_workspace(int B, int Ctot, int N) {
+    if (B <= 0 || Ctot <= 0 || N <= 0) return 64;
+    const int CP = (Ctot * 3 + 15) / 16 * 16;
+    return (size_t)B * N * CP * sizeof(float);
+}
+
+// GPD [B,Ctot,3,N*k] -> gUV [B,2*Ctot,3,N]: gU = scatter-add over idx (row-contiguous atomics), gV = sum over k
+extern "C" int hpcs_edge_grad_reduce(const float* GPD, const int64_t* idx, int B, int Ctot, int N, int k, float* gUV,
+                                     void* ws, size_t ws_bytes, hpcs_stream_t stream) {
+    if (!GPD || !idx || !gUV || !ws) return HPCS_ERR_NULL;
+    if (B < 0 || Ctot <= 0 || N <= 0 || k <= 0 || Ctot > 65535 || B > 65535) return HPCS_ERR_SHAPE;
+    if (B == 0) return HPCS_OK;
+    if (ws_bytes < hpcs_edge_grad_reduce_workspace(B, Ctot, N)) return HPCS_ERR_WORKSPACE;
+    const int64_t L = (int64_t)N * k;
+    const int CP = (Ctot * 3 + 15) / 16 * 16;
+    const bool vec = (k % 4 == 0) && (((uintptr_t)GPD & 15u) == 0);
+    if (vec)
+        hipLaunchKernelGGL((edge_segsum_kernel<true>), dim3(hpcs_cdiv(N, 64), Ctot, B), dim3(64), 0, ST, GPD, Ctot, N, k, gUV);
     else
-        hipLaunchKernelGGL((vn_bwd_apply_kernel<false>), dim3(hpcs_cdiv((int64_t)B * L, TPB), Cout), dim3(TPB), 0, ST, PD,
-                           gout, mean, rstd, gamma, beta, red, training, B, Cout, Cd, L, pool_k, slope, flags, GPD);
+        hipLaunchKernelGGL((edge_segsum_kernel<false>), dim3(hpcs_cdiv(N, 64), Ctot, B), dim3(64), 0, ST, GPD, Ctot, N, k, gUV);
+    HPCS_CHECK_LAUNCH();
+    if (hipMemsetAsync(ws, 0, (size_t)B * N * CP * sizeof(float), ST) != hipSuccess) return HPCS_ERR_HIP;
+    const size_t lds = (size_t)ET * (Ctot * 3 + 1) * sizeof(float);
+    if (lds > 64 * 1024) return HPCS_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(edge_scatter_tile_kernel, dim3(hpcs_cdiv(L, ET), B), dim3(256), lds, ST, GPD, idx, Ctot, Ctot, N, k, CP,
+                       (float*)ws);
+    HPCS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(edge_scatter_fold_kernel, dim3(hpcs_cdiv(N, 64), B), dim3(64), 0, ST, (const float*)ws, Ctot, 2 * Ctot, N,
+                       CP, 0, gUV);
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;
 }

@@ -79,6 +79,19 @@ class VNLinearLeakyReLU(nn.Module):                            # vn_layers.py:48
         return out
 
 
+    def forward_edges(self, feat, idx, pool=False):
+        """Equivalent to forward(get_graph_feature(feat, idx=idx)) [then mean over k if pool], computed from the
+        point features: no [B,2C,3,N,k] edge tensor, and a channel GEMM k times smaller (ops.VNEdgeLayerFn)."""
+        if self.map_to_dir.weight.shape[0] == 1:
+            raise NotImplementedError("shared non-linearity is not used by the EdgeConv layers")
+        bn = self.batchnorm.bn
+        out = ops.vn_edge_layer(feat, idx, self.map_to_feat.weight, self.map_to_dir.weight, bn.weight, bn.bias,
+                                bn.running_mean, bn.running_var, self.training, slope=self.negative_slope, pool=pool)
+        if self.training:
+            bn.num_batches_tracked.add_(1)
+        return out
+
+
 class VNMaxPool(nn.Module):                                    # vn_layers.py:135-149
     def __init__(self, in_channels):
         super().__init__()

@@ -255,6 +255,75 @@ def vn_layer(x, Wf, Wd, gamma, beta, rmean, rvar, training, slope=0.2, pool_k=0,
     return VNLayerFn.apply(x, Wf, Wd, gamma, beta, rmean, rvar, training, slope, pool_k, flags, xconst)
 
 
+class VNEdgeLayerFn(torch.autograd.Function):
+    """get_graph_feature + VNLinearLeakyReLU (+ mean over k) on point features, without any N*k-sized GEMM operand.
+
+    feat [B,C,3,N], idx [B,N,k] -> [B,Cout,3,N,k] (or [B,Cout,3,N] with pool).  W = [Wf;Wd] has 2C columns
+    (difference part | centre part); W [x_nbr-x_ctr; x_ctr] = W_a x_nbr + (W_b-W_a) x_ctr, so one POINT-level GEMM
+    gives UV = [W_a; W_b-W_a] feat and the edge kernels gather from it (include/hpcs_mi355x.h, "gather layers").
+    """
+
+    @staticmethod
+    def forward(ctx, feat, idx, Wf, Wd, gamma, beta, rmean, rvar, training, slope, pool):
+        feat = _f32c(feat)
+        idx = idx.contiguous()
+        B, C, _, N = feat.shape
+        k = idx.shape[-1]
+        Cout, Cd = Wf.shape[0], Wd.shape[0]
+        Ctot = Cout + Cd
+        Wcat = _f32c(torch.cat([Wf, Wd], 0))                       # [Ctot, 2C]
+        Wa, Wb = Wcat[:, :C], Wcat[:, C:]
+        Wuv = torch.cat([Wa, Wb - Wa], 0).contiguous()             # [2Ctot, C]
+        UV = gemm_WX(Wuv, feat, B, C, 3 * N)                       # [B, 2Ctot, 3, N]
+        dev = feat.device
+        mean = torch.empty(Cout, device=dev)
+        rstd = torch.empty(Cout, device=dev)
+        sums = None
+        if training:
+            sums = torch.empty(2 * Cout, device=dev, dtype=torch.float64)
+            call("hpcs_vn_edge_norm_stats", UV, idx, B, Cout, Ctot, N, k, sums)
+        call("hpcs_bn_finalize", sums, Cout, B * N * k, BN_EPS, BN_MOMENTUM, rmean, rvar, mean, rstd, 1 if training else 0)
+        out = torch.empty((B, Cout, 3, N) if pool else (B, Cout, 3, N, k), device=dev)
+        flags = VN_BN | VN_LRELU
+        call("hpcs_vn_edge_apply_fwd", UV, idx, mean, rstd, gamma, beta, B, Cout, Cd, N, k, 1 if pool else 0, slope, flags, out)
+        ctx.save_for_backward(feat, idx, Wuv, UV, mean, rstd, gamma, beta)
+        ctx.cfg = (B, C, N, k, Cout, Cd, bool(pool), slope, flags, bool(training))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        feat, idx, Wuv, UV, mean, rstd, gamma, beta = ctx.saved_tensors
+        B, C, N, k, Cout, Cd, pool, slope, flags, training = ctx.cfg
+        Ctot = Cout + Cd
+        g = _f32c(g)
+        dev = g.device
+        pl = 1 if pool else 0
+        red = torch.empty(2 * Cout, device=dev, dtype=torch.float64)
+        call("hpcs_vn_edge_bwd_reduce", UV, idx, g, mean, rstd, gamma, beta, B, Cout, Cd, N, k, pl, slope, flags, red)
+        GPD = torch.empty(B * Ctot * 3 * N * k, device=dev)
+        call("hpcs_vn_edge_bwd_apply", UV, idx, g, mean, rstd, gamma, beta, red, 1 if training else 0, B, Cout, Cd, N, k, pl,
+             slope, flags, GPD)
+        gUV = torch.empty(B * 2 * Ctot * 3 * N, device=dev)
+        nbytes = call("hpcs_edge_grad_reduce_workspace", B, Ctot, N)
+        ws = torch.empty(nbytes // 4, device=dev)
+        call("hpcs_edge_grad_reduce", GPD, idx, B, Ctot, N, k, gUV, ws, nbytes)
+        del GPD
+        gfeat = gWf = gWd = None
+        if ctx.needs_input_grad[0]:
+            gfeat = gemm_WtG(Wuv, gUV, B, 2 * Ctot, 3 * N).view_as(feat)
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+            gWuv = gemm_GXt(gUV, feat, B, 2 * Ctot, C, 3 * N)                  # [2Ctot, C]
+            gWa = gWuv[:Ctot] - gWuv[Ctot:]
+            gWcat = torch.cat([gWa, gWuv[Ctot:]], dim=1)                       # [Ctot, 2C]
+            gWf, gWd = gWcat[:Cout], gWcat[Cout:]
+        return gfeat, None, gWf, gWd, red[Cout:].float(), red[:Cout].float(), None, None, None, None, None
+
+
+def vn_edge_layer(feat, idx, Wf, Wd, gamma, beta, rmean, rvar, training, slope=0.2, pool=False):
+    _need_cuda(feat, idx, Wf)
+    return VNEdgeLayerFn.apply(feat, idx, Wf, Wd, gamma, beta, rmean, rvar, training, slope, pool)
+
+
 # ------------------------------------------------------------------------------------------------ Conv1d heads
 class BnActFn(torch.autograd.Function):
     """BatchNorm1d over [B,C,L] (+ LeakyReLU(slope)) (* mask)."""

@@ -98,6 +98,29 @@ int hpcs_vn_bwd_apply(const float* PD, const float* gout, const float* mean, con
                       const float* gamma, const float* beta, const double* red, int training, int B, int Cout,
                       int Cd, int64_t L, int pool_k, float slope, int flags, float* GPD, hpcs_stream_t stream);
 
+/* ---- EdgeConv "gather" layers: get_graph_feature + VNLinearLeakyReLU without the N*k tensors ----------------
+ * The first VN layer of an EdgeConv block sees (x[nbr]-x[ctr], x[ctr]) (vn_dgcnn_util.py:33-39), so
+ * W [x_nbr - x_ctr; x_ctr] = W_a x_nbr + (W_b - W_a) x_ctr.  UV [B, 2*Ctot, 3, N] holds the point-level products
+ * U = W_a F (channels [0,Ctot)) and V = (W_b - W_a) F (channels [Ctot,2Ctot)) from ONE k-times-smaller GEMM; the
+ * kernels form PD[b,ch,:,n*k+j] = U[b,ch,:,idx[b,n,j]] + V[b,ch,:,n] on the fly.  Same semantics as the
+ * materialised entry points above with L = N*k; pool != 0 fuses the mean over the k neighbours.
+ * edge_grad_reduce: GPD [B,Ctot,3,N*k] -> gUV (gU = scatter-add over idx, gV = sum over k). */
+int hpcs_vn_edge_norm_stats(const float* UV, const int64_t* idx, int B, int Cout, int Ctot, int N, int k,
+                            double* sums, hpcs_stream_t stream);
+int hpcs_vn_edge_apply_fwd(const float* UV, const int64_t* idx, const float* mean, const float* rstd,
+                           const float* gamma, const float* beta, int B, int Cout, int Cd, int N, int k, int pool,
+                           float slope, int flags, float* out, hpcs_stream_t stream);
+int hpcs_vn_edge_bwd_reduce(const float* UV, const int64_t* idx, const float* gout, const float* mean,
+                            const float* rstd, const float* gamma, const float* beta, int B, int Cout, int Cd, int N,
+                            int k, int pool, float slope, int flags, double* red, hpcs_stream_t stream);
+int hpcs_vn_edge_bwd_apply(const float* UV, const int64_t* idx, const float* gout, const float* mean,
+                           const float* rstd, const float* gamma, const float* beta, const double* red, int training,
+                           int B, int Cout, int Cd, int N, int k, int pool, float slope, int flags, float* GPD,
+                           hpcs_stream_t stream);
+size_t hpcs_edge_grad_reduce_workspace(int B, int Ctot, int N);
+int hpcs_edge_grad_reduce(const float* GPD, const int64_t* idx, int B, int Ctot, int N, int k, float* gUV, void* ws,
+                          size_t ws_bytes, hpcs_stream_t stream);
+
 /* ---- Conv1d(k=1)+BatchNorm1d(+LeakyReLU)(+Dropout mask)  vn_dgcnn_partseg.py:40-57,97-102 ------
  * Y [B,C,L] is the Conv1d output (hpcs_gemm_tn).  slope = 1 means no activation; mask (nullable,
  * [B,C,L]) is the already scaled dropout multiplier. */

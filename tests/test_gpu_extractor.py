@@ -299,3 +299,43 @@ def test_hyp_lca(golden, si, s):
     d.sum().backward()
     relclose(ag.grad, ad.grad, 1e-4)
     relclose(bg.grad, bd.grad, 1e-4)
+
+
+@pytest.mark.parametrize("C,pool", [(1, False), (21, False), (21, True)])
+def test_edge_layer_equals_gather_then_layer(C, pool):
+    """forward_edges (point-level GEMM + in-kernel gather) == VN layer on the materialised graph feature."""
+    from hpcs_amd.nn.dgcnn.utils.vn_layers import VNLinearLeakyReLU
+    from hpcs_amd.nn.dgcnn.utils.vn_dgcnn_util import get_graph_feature
+    B, N, k = 3, 96, 8
+    feat = det_normalish((B, C, 3, N), 800 + C)
+    idx = det_int((B, N, k), 801, N).to(dev)
+    res = []
+    for mode in ("edges", "materialised"):
+        m = load(VNLinearLeakyReLU(2 * C, 21), 802)
+        m.train()
+        fg = feat.to(dev).requires_grad_(True)
+        if mode == "edges":
+            y = m.forward_edges(fg, idx, pool=pool)
+        else:
+            y = m(get_graph_feature(fg, k=k, idx=idx), pool_k=k if pool else 0)
+        w = det_uniform(tuple(y.shape), 803).to(dev)
+        (y * w).sum().backward()
+        res.append((y.detach(), fg.grad, m.map_to_feat.weight.grad, m.map_to_dir.weight.grad, m.batchnorm.bn.weight.grad,
+                    m.batchnorm.bn.bias.grad, m.batchnorm.bn.running_var.clone()))
+    for a, b in zip(*res):
+        relclose(a, b, 2e-5)
+
+
+def test_extractor_gather_mode_close_to_materialised():
+    """The opt-in edge_mode='gather' path computes the same network (up to fp32 reassociation noise)."""
+    from hpcs_amd.nn.dgcnn import VN_DGCNN_partseg
+    net = VN_DGCNN_partseg(3, 8, k=6, dropout=0.0, pooling="mean", num_categories=4)
+    net.load_state_dict(det_params(OE.param_shapes(8, 4), 77))
+    net.to(dev).eval()
+    x = det_cloud(3, 96, 78).to(dev)
+    lab = torch.eye(4)[det_int((3,), 79, 4)].to(dev)
+    with torch.no_grad():
+        y0 = net(x, lab)
+        net.edge_mode = "gather"
+        y1 = net(x, lab)
+    assert float((y0 - y1).norm() / y0.norm()) < 5e-3
