@@ -478,9 +478,19 @@ int launch_hyphc(const float* xn, int E, const int64_t* a, const int64_t* p, con
 }
 
 // ---------------------------------------------------------------------------------------------- CosFace
+// logits = scale * (cos - margin*onehot); loss_row = sum over levels of -log( sum_{c in branch_l(y)} p_c ).
+// A plain CosFace is one level whose branches are the single classes (branch_id == nullptr); the PartNet
+// hierarchical variant (hierarchical_cosface_loss.py:9-28) passes branch_id [n_levels, C].
+constexpr int MAX_LEVELS = 8;
+
+__device__ __forceinline__ bool same_branch(const int32_t* __restrict__ bid, int level, int C, int c, int lab) {
+    return bid ? bid[level * C + c] == bid[level * C + lab] : c == lab;
+}
+
 __global__ void cosface_fwd_kernel(const float* __restrict__ xn, const float* __restrict__ wn, const int64_t* __restrict__ labels,
-                                   int M, int E, int C, float margin, float scale, float* __restrict__ logits,
-                                   float* __restrict__ loss_rows) {
+                                   const int32_t* __restrict__ bid, int n_levels, int M, int E, int C, float margin,
+                                   float scale, float* __restrict__ logits, float* __restrict__ loss_rows,
+                                   float* __restrict__ lse_rows) {
     extern __shared__ float wsh[];          // [C][E]
     for (int i = threadIdx.x; i < C * E; i += blockDim.x) wsh[i] = wn[i];
     __syncthreads();
@@ -503,12 +513,42 @@ __global__ void cosface_fwd_kernel(const float* __restrict__ xn, const float* __
     }
     float se = 0.f;
     for (int c = 0; c < C; ++c) se += expf(lr[c] - mx);
-    loss_rows[row] = (mx + logf(se)) - lr[lab];
+    const float lse = mx + logf(se);
+    float loss = 0.f;
+    for (int l = 0; l < n_levels; ++l) {
+        float sb = 0.f;
+        for (int c = 0; c < C; ++c)
+            if (same_branch(bid, l, C, c, lab)) sb += expf(lr[c] - mx);
+        loss += lse - (mx + logf(sb));
+    }
+    loss_rows[row] = loss;
+    lse_rows[row] = lse;
+}
+
+// d loss_row / d logit_c = n_levels * p_c - sum_l [c in branch_l(y)] p_c / S_l,   S_l = sum_{branch_l(y)} p
+__device__ __forceinline__ void branch_mass(const float* __restrict__ lr, float lse, const int32_t* __restrict__ bid,
+                                            int n_levels, int C, int lab, float (&S)[MAX_LEVELS]) {
+    for (int l = 0; l < n_levels; ++l) {
+        float sb = 0.f;
+        for (int c = 0; c < C; ++c)
+            if (same_branch(bid, l, C, c, lab)) sb += __expf(lr[c] - lse);
+        S[l] = sb;
+    }
+}
+
+__device__ __forceinline__ float dlogit(const float* __restrict__ lr, float lse, const int32_t* __restrict__ bid,
+                                        int n_levels, int C, int lab, int c, const float (&S)[MAX_LEVELS]) {
+    const float pc = __expf(lr[c] - lse);
+    float d = (float)n_levels * pc;
+    for (int l = 0; l < n_levels; ++l)
+        if (same_branch(bid, l, C, c, lab)) d -= pc / S[l];
+    return d;
 }
 
 // grad wrt xn rows; one thread per row
 __global__ void cosface_bwd_x_kernel(const float* __restrict__ wn, const int64_t* __restrict__ labels,
-                                     const float* __restrict__ logits, int M, int E, int C, float scale,
+                                     const float* __restrict__ logits, const float* __restrict__ lse_rows,
+                                     const int32_t* __restrict__ bid, int n_levels, int M, int E, int C, float scale,
                                      const float* __restrict__ gloss, float* __restrict__ gxn) {
     extern __shared__ float wsh[];
     const float gmean = *gloss / (float)M;
@@ -518,17 +558,13 @@ __global__ void cosface_bwd_x_kernel(const float* __restrict__ wn, const int64_t
     if (row >= M) return;
     const int lab = (int)labels[row];
     const float* lr = logits + (int64_t)row * C;
-    float mx = -INFINITY;
-    for (int c = 0; c < C; ++c) mx = fmaxf(mx, lr[c]);
-    float se = 0.f;
-    for (int c = 0; c < C; ++c) se += expf(lr[c] - mx);
-    const float inv = 1.f / se;
+    const float lse = lse_rows[row];
+    float S[MAX_LEVELS];
+    branch_mass(lr, lse, bid, n_levels, C, lab, S);
     for (int e = 0; e < E; ++e) {
         float acc = 0.f;
-        for (int c = 0; c < C; ++c) {
-            const float dl = (expf(lr[c] - mx) * inv - (c == lab ? 1.f : 0.f)) * gmean * scale;
-            acc = __builtin_fmaf(dl, wsh[c * E + e], acc);
-        }
+        for (int c = 0; c < C; ++c)
+            acc = __builtin_fmaf(dlogit(lr, lse, bid, n_levels, C, lab, c, S) * gmean * scale, wsh[c * E + e], acc);
         gxn[(int64_t)row * E + e] += acc;
     }
 }
@@ -536,19 +572,21 @@ __global__ void cosface_bwd_x_kernel(const float* __restrict__ wn, const int64_t
 // grad wrt wn [C,E]: each workgroup takes a slab of rows, stages d(logit) [rows][C] in LDS, then thread o=(c,e)
 // reduces the slab and issues ONE atomic per output.
 __global__ void cosface_bwd_w_kernel(const float* __restrict__ xn, const int64_t* __restrict__ labels,
-                                     const float* __restrict__ logits, const float* __restrict__ loss_rows, int M, int E,
-                                     int C, float scale, const float* __restrict__ gloss, int rows_per_block,
-                                     float* __restrict__ gwn) {
+                                     const float* __restrict__ logits, const float* __restrict__ lse_rows,
+                                     const int32_t* __restrict__ bid, int n_levels, int M, int E, int C, float scale,
+                                     const float* __restrict__ gloss, int rows_per_block, float* __restrict__ gwn) {
     extern __shared__ float dl[];        // [rows_per_block][C]
     const float gmean = *gloss / (float)M;
     const int r0 = blockIdx.x * rows_per_block;
     const int nr = min(rows_per_block, M - r0);
-    for (int i = threadIdx.x; i < nr * C; i += blockDim.x) {
-        const int row = r0 + i / C, c = i % C;
+    for (int r = threadIdx.x; r < nr; r += blockDim.x) {
+        const int row = r0 + r;
         const int lab = (int)labels[row];
         const float* lr = logits + (int64_t)row * C;
-        const float lse = loss_rows[row] + lr[lab];
-        dl[i] = (__expf(lr[c] - lse) - (c == lab ? 1.f : 0.f)) * gmean * scale;
+        const float lse = lse_rows[row];
+        float S[MAX_LEVELS];
+        branch_mass(lr, lse, bid, n_levels, C, lab, S);
+        for (int c = 0; c < C; ++c) dl[r * C + c] = dlogit(lr, lse, bid, n_levels, C, lab, c, S) * gmean * scale;
     }
     __syncthreads();
     for (int o = threadIdx.x; o < C * E; o += blockDim.x) {
@@ -727,35 +765,35 @@ extern "C" int hpcs_hyphc_bwd(const float* xn, int E, const int64_t* a, const in
     return HPCS_OK;
 }
 
-extern "C" int hpcs_cosface_fwd(const float* xn, const float* wn, const int64_t* labels, int M, int E, int C, float margin,
-                                float scale, float* logits, float* loss_rows, hpcs_stream_t stream) {
-    if (!xn || !wn || !labels || !logits || !loss_rows) return HPCS_ERR_NULL;
+extern "C" int hpcs_cosface_fwd(const float* xn, const float* wn, const int64_t* labels, const int32_t* branch_id,
+                                int n_levels, int M, int E, int C, float margin, float scale, float* logits,
+                                float* loss_rows, float* lse_rows, hpcs_stream_t stream) {
+    if (!xn || !wn || !labels || !logits || !loss_rows || !lse_rows) return HPCS_ERR_NULL;
     if (M < 0 || E <= 0 || C <= 0 || (size_t)C * E * 4 > 64 * 1024) return HPCS_ERR_SHAPE;
+    if (n_levels < 1 || n_levels > MAX_LEVELS || (n_levels > 1 && !branch_id)) return HPCS_ERR_SHAPE;
     if (M == 0) return HPCS_OK;
-    hipLaunchKernelGGL(cosface_fwd_kernel, dim3(hpcs_cdiv(M, 64)), dim3(64), (size_t)C * E * 4, ST, xn, wn, labels, M, E, C,
-                       margin, scale, logits, loss_rows);
+    hipLaunchKernelGGL(cosface_fwd_kernel, dim3(hpcs_cdiv(M, 64)), dim3(64), (size_t)C * E * 4, ST, xn, wn, labels, branch_id,
+                       n_levels, M, E, C, margin, scale, logits, loss_rows, lse_rows);
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;
 }
 
 extern "C" int hpcs_cosface_bwd(const float* xn, const float* wn, const int64_t* labels, const float* logits,
-                                const float* loss_rows, int M, int E, int C, float scale, const float* gloss, float* gxn,
-                                float* gwn, hpcs_stream_t stream) {
-    if (!xn || !wn || !labels || !logits || !loss_rows || !gloss || !gxn || !gwn) return HPCS_ERR_NULL;
+                                const float* lse_rows, const int32_t* branch_id, int n_levels, int M, int E, int C,
+                                float scale, const float* gloss, float* gxn, float* gwn, hpcs_stream_t stream) {
+    if (!xn || !wn || !labels || !logits || !lse_rows || !gloss || !gxn || !gwn) return HPCS_ERR_NULL;
     if (M < 0 || E <= 0 || C <= 0 || (size_t)C * E * 4 > 64 * 1024) return HPCS_ERR_SHAPE;
-    if (M == 0) {
-        if (hipMemsetAsync(gwn, 0, sizeof(float) * C * E, ST) != hipSuccess) return HPCS_ERR_HIP;
-        return HPCS_OK;
-    }
-    hipLaunchKernelGGL(cosface_bwd_x_kernel, dim3(hpcs_cdiv(M, 64)), dim3(64), (size_t)C * E * 4, ST, wn, labels, logits, M, E,
-                       C, scale, gloss, gxn);
-    HPCS_CHECK_LAUNCH();
+    if (n_levels < 1 || n_levels > MAX_LEVELS || (n_levels > 1 && !branch_id)) return HPCS_ERR_SHAPE;
     if (hipMemsetAsync(gwn, 0, sizeof(float) * C * E, ST) != hipSuccess) return HPCS_ERR_HIP;
+    if (M == 0) return HPCS_OK;
+    hipLaunchKernelGGL(cosface_bwd_x_kernel, dim3(hpcs_cdiv(M, 64)), dim3(64), (size_t)C * E * 4, ST, wn, labels, logits,
+                       lse_rows, branch_id, n_levels, M, E, C, scale, gloss, gxn);
+    HPCS_CHECK_LAUNCH();
     int rpb = (48 * 1024) / (4 * C);
     if (rpb > 256) rpb = 256;
     if (rpb < 1) return HPCS_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(cosface_bwd_w_kernel, dim3(hpcs_cdiv(M, rpb)), dim3(TPB), (size_t)rpb * C * 4, ST, xn, labels, logits,
-                       loss_rows, M, E, C, scale, gloss, rpb, gwn);
+                       lse_rows, branch_id, n_levels, M, E, C, scale, gloss, rpb, gwn);
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;
 }

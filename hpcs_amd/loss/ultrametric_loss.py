@@ -88,14 +88,16 @@ class HypHCFn(torch.autograd.Function):
 
 class CosFaceFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xn, wn, labels, margin, scale):
+    def forward(ctx, xn, wn, labels, margin, scale, branch_id):
         M, E = xn.shape
         C = wn.shape[0]
+        n_levels = 1 if branch_id is None else branch_id.shape[0]
         logits = torch.empty(M, C, device=xn.device, dtype=torch.float32)
         rows = torch.empty(M, device=xn.device, dtype=torch.float32)
-        call("hpcs_cosface_fwd", xn, wn, labels, M, E, C, margin, scale, logits, rows)
-        ctx.save_for_backward(xn, wn, labels, logits, rows)
-        ctx.scale = scale
+        lse = torch.empty(M, device=xn.device, dtype=torch.float32)
+        call("hpcs_cosface_fwd", xn, wn, labels, branch_id, n_levels, M, E, C, margin, scale, logits, rows, lse)
+        ctx.save_for_backward(xn, wn, labels, logits, lse, branch_id)
+        ctx.cfg = (scale, n_levels)
         ctx.mark_non_differentiable(logits)
         mean = torch.empty(1, device=xn.device, dtype=torch.float32)
         call("hpcs_rowsum", rows, 1, M, 1.0 / M, mean)
@@ -103,13 +105,15 @@ class CosFaceFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g, _glogits):
-        xn, wn, labels, logits, rows = ctx.saved_tensors
+        xn, wn, labels, logits, lse, branch_id = ctx.saved_tensors
+        scale, n_levels = ctx.cfg
         M, E = xn.shape
         C = wn.shape[0]
         gxn = torch.zeros_like(xn)
         gwn = torch.empty_like(wn)
-        call("hpcs_cosface_bwd", xn, wn, labels, logits, rows, M, E, C, ctx.scale, g.reshape(1).contiguous().float(), gxn, gwn)
-        return gxn, gwn, None, None, None
+        call("hpcs_cosface_bwd", xn, wn, labels, logits, lse, branch_id, n_levels, M, E, C, scale,
+             g.reshape(1).contiguous().float(), gxn, gwn)
+        return gxn, gwn, None, None, None, None
 
 
 class CosFaceLoss(torch.nn.Module):
@@ -123,16 +127,38 @@ class CosFaceLoss(torch.nn.Module):
         self.scale = scale
         self.W = torch.nn.Parameter(torch.Tensor(embedding_size, num_classes))
         torch.nn.init.normal_(self.W)
+        self.branch_id = None
 
     def logits_and_loss(self, embeddings, labels, xn=None):
         if xn is None:
             xn = L2RowsFn.apply(embeddings)
         wn = L2RowsFn.apply(self.W.t())
+        bid = self.branch_id
+        if bid is not None and bid.device != xn.device:
+            bid = self.branch_id = bid.to(xn.device)
         return CosFaceFn.apply(xn, wn, labels.reshape(-1).to(torch.int64).contiguous(), float(self.margin),
-                               float(self.scale))
+                               float(self.scale), bid)
 
     def forward(self, embeddings, labels, xn=None):
         return self.logits_and_loss(embeddings, labels, xn)[0]
+
+
+class HierarchicalCosFaceLoss(CosFaceLoss):
+    """hpcs/loss/hierarchical_cosface_loss.py:31-87: CosFace logits -> softmax -> per hierarchy level the class
+    probabilities of a branch are replaced by the branch sum -> NLL; levels are summed.
+    hierarchy_list: [level][branch][class ids] (hpcs/data/hierarchy_list.py:9-19)."""
+
+    def __init__(self, num_classes, embedding_size, margin=0.35, scale=64, hierarchy_list=None):
+        super().__init__(num_classes, embedding_size, margin=margin, scale=scale)
+        self.hierarchy_list = hierarchy_list or []
+        if not 1 <= len(self.hierarchy_list) <= 8:
+            raise ValueError("hierarchy_list must hold 1..8 levels")
+        bid = torch.arange(num_classes, dtype=torch.int32).repeat(len(self.hierarchy_list), 1) + num_classes
+        for lv, level in enumerate(self.hierarchy_list):
+            for j, branch in enumerate(level):
+                for ch in branch:
+                    bid[lv, ch] = j
+        self.branch_id = bid.contiguous()
 
 
 class MetricHyperbolicLoss(torch.nn.Module):
@@ -237,3 +263,18 @@ class MetricHyperbolicLoss(torch.nn.Module):
         """Unit rows times clamp(scale, 1e-4, 1) (ultrametric_loss.py:139-143)."""
         s = self._scale_tensor(embeddings)
         return L2RowsFn.apply(embeddings) * torch.clamp(s, 1e-4, 1)
+
+
+class HierarchicalMetricHyperbolicLoss(MetricHyperbolicLoss):
+    """hpcs/loss/ultrametric_loss.py:146-176: the PartNet default -- HypHC term + hierarchical CosFace."""
+
+    def __init__(self, margin: float = 1.0, t_per_anchor: int = 50, fraction: float = 1.2,
+                 scale: Union[float, torch.Tensor, torch.nn.Parameter] = 1e-3, temperature: float = 0.05,
+                 anneal_factor: float = 0.5, num_class: int = 4, embedding_size: int = 4, miner: bool = False,
+                 hierarchy_list: list = [], rng: str = "host", fused_filter: bool = False):
+        super().__init__(margin=margin, t_per_anchor=t_per_anchor, fraction=fraction, scale=scale,
+                         temperature=temperature, anneal_factor=anneal_factor, num_class=num_class,
+                         embedding_size=embedding_size, cosface=True, miner=miner, rng=rng, fused_filter=fused_filter)
+        self.hierarchy_list = hierarchy_list
+        self.loss_cosface = HierarchicalCosFaceLoss(num_classes=num_class, embedding_size=embedding_size, margin=0.35,
+                                                    scale=2, hierarchy_list=hierarchy_list)

@@ -218,12 +218,17 @@ int hpcs_hyphc_bwd(const float* xn, int E, const int64_t* a, const int64_t* p, c
                    hpcs_stream_t stream);
 /* mean of the M x M similarity in closed form: 0.5 + 0.5*|sum_i xn_i|^2/M^2.  colsum [E] double. */
 int hpcs_colsum(const float* xn, int64_t rows, int E, double* colsum, hpcs_stream_t stream);
-int hpcs_cosface_fwd(const float* xn, const float* wn, const int64_t* labels, int M, int E, int C, float margin,
-                     float scale, float* logits, float* loss_rows, hpcs_stream_t stream);
-/* bwd: gxn [M,E] is ACCUMULATED into, gwn [C,E] is overwritten; gloss = device scalar dL/d(mean loss) */
+/* cosface: plain CosFace = one level of singleton branches (branch_id NULL, n_levels 1).  Hierarchical CosFace
+ * (next row f2: hierarchical_loss + HierarchicalCosFaceLoss, hpcs/loss/hierarchical_cosface_loss.py:9-87):
+ * branch_id [n_levels, C] int32 gives each class its branch per level; loss_row = sum_l -log(sum_{c in branch_l(y)} p_c).
+ * fwd writes logits [M,C], loss_rows [M], lse_rows [M].
+ * bwd: gxn [M,E] is ACCUMULATED into, gwn [C,E] is overwritten; gloss = device scalar dL/d(mean loss). */
+int hpcs_cosface_fwd(const float* xn, const float* wn, const int64_t* labels, const int32_t* branch_id, int n_levels,
+                     int M, int E, int C, float margin, float scale, float* logits, float* loss_rows,
+                     float* lse_rows, hpcs_stream_t stream);
 int hpcs_cosface_bwd(const float* xn, const float* wn, const int64_t* labels, const float* logits,
-                     const float* loss_rows, int M, int E, int C, float scale, const float* gloss, float* gxn,
-                     float* gwn, hpcs_stream_t stream);
+                     const float* lse_rows, const int32_t* branch_id, int n_levels, int M, int E, int C, float scale,
+                     const float* gloss, float* gxn, float* gwn, hpcs_stream_t stream);
 int hpcs_triplet_margin_fwd(const float* xn, int E, const int64_t* a, const int64_t* p, const int64_t* n,
                             const int64_t* count, int64_t T_cap, float margin, double* sum_and_nnz,
                             hpcs_stream_t stream);

@@ -201,3 +201,35 @@ def test_radam_matches_reference(golden):
     for i, p_ in enumerate(ps):
         close(opt.state[p_]["exp_avg"], golden[f"radam_final_m{i}"], rtol=2e-5, atol=1e-7)
         close(opt.state[p_]["exp_avg_sq"], golden[f"radam_final_v{i}"], rtol=2e-5, atol=1e-9)
+
+
+def test_hierarchical_cosface_loss_and_grads():
+    """Next row f2: HierarchicalMetricHyperbolicLoss's metric term vs the oracle restatement (fp64)."""
+    from hpcs_amd.loss.ultrametric_loss import HierarchicalMetricHyperbolicLoss
+    M, E, C = 700, 16, 9
+    hier = [[[0, 1, 2], [3, 4], [5, 6, 7, 8]], [[0], [1, 2], [3], [4], [5, 6], [7, 8]], [[c] for c in range(C)]]
+    x = OH.expmap0(det_normalish((M, E), 51) * 0.6)
+    lab = det_int((M,), 52, C)
+    crit = HierarchicalMetricHyperbolicLoss(t_per_anchor=6, fraction=1.2, scale=torch.nn.Parameter(torch.tensor([0.05])),
+                                            num_class=C, embedding_size=E, miner=True, hierarchy_list=hier).to(dev)
+    W = det_normalish((E, C), 53)
+    crit.loss_cosface.W.data.copy_(W)
+    xg = x.to(dev).requires_grad_(True)
+    torch.manual_seed(2)
+    out = crit.compute_loss(None, xg, lab.to(dev))
+    lm = out["loss_metric"]["losses"]
+    x64 = x.double().requires_grad_(True)
+    W64 = W.double().requires_grad_(True)
+    want = OM.hierarchical_cosface_loss(x64, lab, W64, hier, 0.35, 2.0)
+    assert abs(float(lm) - float(want)) <= 1e-5 * abs(float(want))
+    lm.backward()
+    want.backward()
+    relclose(xg.grad, x64.grad, 2e-4)
+    relclose(crit.loss_cosface.W.grad, W64.grad, 2e-4)
+    # the last level is the flat classification: a single flat level must equal the plain CosFace loss
+    from hpcs_amd.loss.ultrametric_loss import CosFaceLoss, HierarchicalCosFaceLoss
+    flat = HierarchicalCosFaceLoss(C, E, 0.35, 2, hierarchy_list=[[[c] for c in range(C)]]).to(dev)
+    plain = CosFaceLoss(C, E, 0.35, 2).to(dev)
+    flat.W.data.copy_(W)
+    plain.W.data.copy_(W)
+    assert abs(float(flat(x.to(dev), lab.to(dev))) - float(plain(x.to(dev), lab.to(dev)))) < 1e-6
