@@ -45,6 +45,7 @@ class L2RowsFn(torch.autograd.Function):
 
 
 _KIND = {None: -1, "all": 0, "easy": 1, "semihard": 2, "hard": 3}
+_LAST_KEPT = [None]          # device int64 tensor: number of triplets the last HypHC forward averaged over
 
 
 class HypHCFn(torch.autograd.Function):
@@ -63,6 +64,7 @@ class HypHCFn(torch.autograd.Function):
         kept = torch.empty(1, dtype=torch.int64, device=dev) if kid >= 0 else None
         call("hpcs_hyphc_fwd", xn, E, a, p, n, count, a.numel(), scale, temperature, margin, kid, loss_sum, kept)
         norm = kept if kid >= 0 else count
+        _LAST_KEPT[0] = norm
         colsum = torch.empty(E, dtype=torch.float64, device=dev)
         call("hpcs_colsum", xn, M, E, colsum)
         mean_sim = 0.5 + 0.5 * (colsum * colsum).sum() / float(M * M)
@@ -228,7 +230,9 @@ class MetricHyperbolicLoss(torch.nn.Module):
         a, p, n, count = triplets
         self.last_triplets = triplets
         scale = self._scale_tensor(xn)
-        return HypHCFn.apply(xn, scale, a, p, n, count, float(self.temperature), margin, kind)
+        out = HypHCFn.apply(xn, scale, a, p, n, count, float(self.temperature), margin, kind)
+        self.last_kept = _LAST_KEPT[0]
+        return out
 
     def get_logits(self, embeddings, labels):
         if not hasattr(self, "loss_cosface"):
