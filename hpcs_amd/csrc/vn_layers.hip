@@ -674,6 +674,97 @@ __global__ void frame_project_bwd_kernel(const float* __restrict__ x, const floa
     for (int t = 0; t < 9; ++t) gz[((int64_t)b * 9 + t) * N + m] = gzz[t];
 }
 
+// Fused invariant projection + max over N (vn_layers.py:197 einsum followed by vn_dgcnn_partseg.py:86-87's max):
+// out[b, i, k] = max_n sum_j xi[b,i,j,(n)] z[b,j,k,n], where channel i < C reads x [B,C,3,N] and channel i >= C reads
+// the per-cloud constant xc [B,Cc,3] (the mean half of cat(x, mean_N(x))).  The [B,C+Cc,3,N] projected tensor is never
+// written; argmax (first index on ties) is kept for the sparse backward.  One workgroup per (b, i).
+__global__ void project_max_fwd_kernel(const float* __restrict__ x, const float* __restrict__ xc, const float* __restrict__ z,
+                                       int C, int Cc, int N, float* __restrict__ out, int32_t* __restrict__ arg) {
+    __shared__ float sv[3][4];
+    __shared__ int si[3][4];
+    const int i = blockIdx.x, b = blockIdx.y;
+    const float* zp = z + (int64_t)b * 9 * N;
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    const float* xp = nullptr;
+    if (i < C) {
+        xp = x + ((int64_t)(b * C + i) * 3) * N;
+    } else {
+        const float* q = xc + (int64_t)(b * Cc + (i - C)) * 3;
+        c0 = q[0]; c1 = q[1]; c2 = q[2];
+    }
+    float bv[3] = {-INFINITY, -INFINITY, -INFINITY};
+    int bi[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        const float x0 = xp ? xp[n] : c0, x1 = xp ? xp[N + n] : c1, x2 = xp ? xp[2 * (int64_t)N + n] : c2;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float v = x0 * zp[(int64_t)(0 * 3 + k) * N + n] + x1 * zp[(int64_t)(1 * 3 + k) * N + n] +
+                            x2 * zp[(int64_t)(2 * 3 + k) * N + n];
+            if (v > bv[k]) { bv[k] = v; bi[k] = n; }
+        }
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float v = bv[k];
+        int ix = bi[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(v, o, 64);
+            const int oi = __shfl_xor(ix, o, 64);
+            if (ov > v || (ov == v && oi < ix)) { v = ov; ix = oi; }
+        }
+        if (lane == 0) { sv[k][w] = v; si[k][w] = ix; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int k = threadIdx.x;
+        float v = sv[k][0];
+        int ix = si[k][0];
+        for (int j = 1; j < nw; ++j)
+            if (sv[k][j] > v || (sv[k][j] == v && si[k][j] < ix)) { v = sv[k][j]; ix = si[k][j]; }
+        const int64_t o = ((int64_t)b * (C + Cc) + i) * 3 + k;
+        out[o] = v;
+        arg[o] = ix;
+    }
+}
+
+// sparse backward: thread per (b, i); gx / gz must be zero-filled by the caller (gz via atomics)
+__global__ void project_max_bwd_kernel(const float* __restrict__ x, const float* __restrict__ xc, const float* __restrict__ z,
+                                       const int32_t* __restrict__ arg, const float* __restrict__ gout, int B, int C, int Cc,
+                                       int N, float* __restrict__ gx, float* __restrict__ gxc, float* __restrict__ gz) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int Ct = C + Cc;
+    if (t >= (int64_t)B * Ct) return;
+    const int b = (int)(t / Ct), i = (int)(t % Ct);
+    const float* zp = z + (int64_t)b * 9 * N;
+    float gc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int n = arg[t * 3 + k];
+        const float g = gout[t * 3 + k];
+        float xv[3];
+        if (i < C) {
+            const float* xp = x + ((int64_t)(b * C + i) * 3) * N;
+            xv[0] = xp[n]; xv[1] = xp[N + n]; xv[2] = xp[2 * (int64_t)N + n];
+        } else {
+            const float* q = xc + (int64_t)(b * Cc + (i - C)) * 3;
+            xv[0] = q[0]; xv[1] = q[1]; xv[2] = q[2];
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float zjk = zp[(int64_t)(j * 3 + k) * N + n];
+            if (i < C) atomicAdd(gx + ((int64_t)(b * C + i) * 3 + j) * N + n, g * zjk);   // the 3 k's may share n
+            else gc[j] += g * zjk;
+            atomicAdd(gz + ((int64_t)b * 9 + j * 3 + k) * N + n, g * xv[j]);
+        }
+    }
+    if (i >= C) {
+        float* q = gxc + (int64_t)(b * Cc + (i - C)) * 3;
+        q[0] = gc[0]; q[1] = gc[1]; q[2] = gc[2];
+    }
+}
+
 __global__ void rowmax_fwd_kernel(const float* __restrict__ x, int64_t L, float* __restrict__ out, int32_t* __restrict__ arg) {
     __shared__ float sv[16];
     __shared__ int si[16];
@@ -1088,6 +1179,30 @@ extern "C" int hpcs_frame_project_bwd(const float* x, const float* z, const floa
     if (B < 0 || C <= 0 || N <= 0 || B > 65535) return HPCS_ERR_SHAPE;
     if (B == 0) return HPCS_OK;
     hipLaunchKernelGGL(frame_project_bwd_kernel, dim3(hpcs_cdiv(N, 64), B), dim3(64), 0, ST, x, z, gout, C, N, gx, gz);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
+extern "C" int hpcs_project_max_fwd(const float* x, const float* xconst, const float* z, int B, int C, int Cc, int N,
+                                    float* out, int32_t* arg, hpcs_stream_t stream) {
+    if (!x || !z || !out || !arg || (Cc > 0 && !xconst)) return HPCS_ERR_NULL;
+    if (B < 0 || C <= 0 || Cc < 0 || N <= 0 || B > 65535) return HPCS_ERR_SHAPE;
+    if (B == 0) return HPCS_OK;
+    hipLaunchKernelGGL(project_max_fwd_kernel, dim3(C + Cc, B), dim3(256), 0, ST, x, xconst, z, C, Cc, N, out, arg);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
+extern "C" int hpcs_project_max_bwd(const float* x, const float* xconst, const float* z, const int32_t* arg,
+                                    const float* gout, int B, int C, int Cc, int N, float* gx, float* gxconst, float* gz,
+                                    hpcs_stream_t stream) {
+    if (!x || !z || !arg || !gout || !gx || !gz || (Cc > 0 && (!xconst || !gxconst))) return HPCS_ERR_NULL;
+    if (B < 0 || C <= 0 || Cc < 0 || N <= 0) return HPCS_ERR_SHAPE;
+    if (B == 0) return HPCS_OK;
+    if (hipMemsetAsync(gx, 0, sizeof(float) * (size_t)B * C * 3 * N, ST) != hipSuccess) return HPCS_ERR_HIP;
+    if (hipMemsetAsync(gz, 0, sizeof(float) * (size_t)B * 9 * N, ST) != hipSuccess) return HPCS_ERR_HIP;
+    hipLaunchKernelGGL(project_max_bwd_kernel, dim3(hpcs_cdiv((int64_t)B * (C + Cc), 128)), dim3(128), 0, ST, x, xconst, z, arg,
+                       gout, B, C, Cc, N, gx, gxconst, gz);
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;
 }

@@ -120,10 +120,10 @@ class VN_DGCNN_partseg(nn.Module):
         gbar = ops.RowMeanFn.apply(g6)                                          # [B,341,3] mean over N
         # vn1 sees cat(g6, mean expanded) (:82-83): the N-constant half enters its GEMM as a row bias
         z0 = self.std_feature.frame(g6, xconst=gbar)                            # [B,3,3,N]
-        g = ops.ConcatMeanFn.apply(g6)                                          # [B,682,3,N] (for the projection)
-        g_std = ops.FrameProjectFn.apply(g, z0)
+        # invariant global feature: max over N of the frame projection of cat(g6, mean) (:84-87), fused -- the
+        # [B,682,3,N] concatenation and its projection are never materialised, and the backward is sparse
+        glob = ops.ProjectMaxFn.apply(g6, gbar, z0)                             # [B,2046]
         loc = ops.FrameProjectFn.apply(x123, z0).view(B, -1, N)                 # [B,189,N]
-        glob = ops.RowMaxFn.apply(g_std.view(B, -1, N))                         # [B,2046]
 
         cat = self._head(self.conv7, l.view(B, -1, 1).float())                  # [B,64,1]
         vec = torch.cat((glob, cat.view(B, -1)), dim=1)                         # [B,2110]

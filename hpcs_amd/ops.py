@@ -405,6 +405,33 @@ class FrameProjectFn(torch.autograd.Function):
         return gx, gz
 
 
+class ProjectMaxFn(torch.autograd.Function):
+    """max over N of einsum('bijm,bjkm->bikm', cat(x, xconst expanded over N), z) -> [B, (C+Cc)*3], fused."""
+
+    @staticmethod
+    def forward(ctx, x, xconst, z):
+        x, z = _f32c(x), _f32c(z)
+        B, C, _, N = x.shape
+        Cc = 0 if xconst is None else xconst.shape[1]
+        xc = None if xconst is None else _f32c(xconst)
+        out = torch.empty(B, (C + Cc) * 3, device=x.device)
+        arg = torch.empty(B, (C + Cc) * 3, device=x.device, dtype=torch.int32)
+        call("hpcs_project_max_fwd", x, xc, z, B, C, Cc, N, out, arg)
+        ctx.save_for_backward(x, xc, z, arg)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, xc, z, arg = ctx.saved_tensors
+        B, C, _, N = x.shape
+        Cc = 0 if xc is None else xc.shape[1]
+        gx = torch.empty_like(x)
+        gz = torch.empty_like(z)
+        gxc = None if xc is None else torch.empty_like(xc)
+        call("hpcs_project_max_bwd", x, xc, z, arg, _f32c(g), B, C, Cc, N, gx, gxc, gz)
+        return gx, gxc, gz
+
+
 class RowMaxFn(torch.autograd.Function):
     """max over the last dim (values only differentiable)."""
 

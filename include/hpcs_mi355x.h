@@ -144,6 +144,13 @@ int hpcs_concat_mean_bwd(const float* gout, int B, int C, int N, float* gx, hpcs
 int hpcs_frame_project_fwd(const float* x, const float* z, int B, int C, int N, float* out, hpcs_stream_t stream);
 int hpcs_frame_project_bwd(const float* x, const float* z, const float* gout, int B, int C, int N, float* gx,
                            float* gz, hpcs_stream_t stream);
+/* project_max: fused frame_project + max over N for cat(x [B,C,3,N], xconst [B,Cc,3] expanded) (vn_dgcnn_partseg.py
+ * :82-87): out/arg [B, C+Cc, 3]; the projected [B,C+Cc,3,N] tensor is never written.  bwd is sparse (argmax only):
+ * gx [B,C,3,N] and gz [B,3,3,N] are overwritten (zero-filled, then atomics), gxconst [B,Cc,3] overwritten. */
+int hpcs_project_max_fwd(const float* x, const float* xconst, const float* z, int B, int C, int Cc, int N, float* out,
+                         int32_t* arg, hpcs_stream_t stream);
+int hpcs_project_max_bwd(const float* x, const float* xconst, const float* z, const int32_t* arg, const float* gout,
+                         int B, int C, int Cc, int N, float* gx, float* gxconst, float* gz, hpcs_stream_t stream);
 int hpcs_rowmax_fwd(const float* x, int64_t rows, int64_t L, float* out, int32_t* arg, hpcs_stream_t stream);
 int hpcs_rowmax_bwd(const float* gout, const int32_t* arg, int64_t rows, int64_t L, float* gx,
                     hpcs_stream_t stream);

@@ -339,3 +339,24 @@ def test_extractor_gather_mode_close_to_materialised():
         net.edge_mode = "gather"
         y1 = net(x, lab)
     assert float((y0 - y1).norm() / y0.norm()) < 5e-3
+
+
+def test_project_max_equals_unfused():
+    from hpcs_amd import ops
+    B, C, N = 3, 7, 200
+    x = det_normalish((B, C, 3, N), 900)
+    z = det_normalish((B, 3, 3, N), 901)
+    res = []
+    for fused in (True, False):
+        xg = x.to(dev).requires_grad_(True)
+        zg = z.to(dev).requires_grad_(True)
+        if fused:
+            y = ops.ProjectMaxFn.apply(xg, ops.RowMeanFn.apply(xg), zg)
+        else:
+            cat = ops.ConcatMeanFn.apply(xg)
+            y = ops.RowMaxFn.apply(ops.FrameProjectFn.apply(cat, zg).view(B, -1, N))
+        w = det_uniform(tuple(y.shape), 902).to(dev)
+        (y * w).sum().backward()
+        res.append((y.detach(), xg.grad, zg.grad))
+    for a, b in zip(*res):
+        relclose(a, b, 1e-5)
