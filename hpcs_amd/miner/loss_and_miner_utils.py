@@ -74,12 +74,13 @@ def sample_with_plan(labels, plan, rng="host", seed=0):
     offsets = torch.empty(C + 1, dtype=torch.int32, device=dev)
     counts_ws = torch.empty(C, dtype=torch.int32, device=dev)
     _lib.call("hpcs_class_index", labels, M, C, order, offsets, counts_ws)
-    toff = plan.toff.to(dev, non_blocking=True)
-    kk = plan.k.to(dev, non_blocking=True)
+    from .._pinned import upload
+    toff = upload(plan.toff, dev, key="plan")
+    kk = upload(plan.k, dev, key="plan")
     dp = dn = None
     if rng == "host":
         hp, hn = plan.host_draws()
-        dp, dn = hp.to(dev), hn.to(dev)
+        dp, dn = upload(hp, dev, key="draws"), upload(hn, dev, key="draws")
     elif rng != "device":
         raise ValueError("rng must be 'host' or 'device'")
     _lib.call("hpcs_sample_triplets", order, offsets, toff, kk, C, M, T, dp, dn, int(seed) & (2 ** 63 - 1), a, p, n)

@@ -66,7 +66,8 @@ class RAdam(torch.optim.Adam):
             if not params:
                 continue
             host, rows_total = self._table(group, params)
-            dev_table = host.to(params[0].device, non_blocking=False)
+            from .._pinned import upload
+            dev_table = upload(host, params[0].device, key="radam")       # async, through a pinned ring
             b1, b2 = group["betas"]
             _lib.call("hpcs_radam_step", dev_table, len(params), rows_total, b1, b2, group["eps"], group["weight_decay"])
             self._keep = dev_table     # keep the table alive until the kernel has consumed it
