@@ -332,7 +332,7 @@ __global__ __launch_bounds__(TPB) void hyphc_kernel(const float* __restrict__ xn
         IO::load(xn, E, in, s, nv);
     };
 
-    double acc = 0.0;
+    double acc = 0.0, acc_loss = 0.0;
     float acc_a[EPL];
     int64_t cur = -1;
 #pragma unroll
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(TPB) void hyphc_kernel(const float* __restrict__ xn
         if (kind >= 0) {
             const float tm = 0.5f * (1.f + d1) - 0.5f * (1.f + d2);
             live = live && keep_rule(tm, margin, kind);
-            if (!BWD && live && s == 0) ++kept;
+            if (live && s == 0) ++kept;
         }
         // lane s (<3) of the group evaluates similarity s; lanes >= 3 shadow similarity 2
         const float my_dot = s == 0 ? d1 : (s == 1 ? d2 : d3);
@@ -373,6 +373,7 @@ __global__ __launch_bounds__(TPB) void hyphc_kernel(const float* __restrict__ xn
         if (!BWD) {
             if (live && s == 0) acc += (double)((w0 + w1 + w2) - wbar);
         } else {
+            if (live && s == 0) acc_loss += (double)((w0 + w1 + w2) - wbar);
             const float my_w = s == 0 ? w0 : (s == 1 ? w1 : w2);
             const float sm = ex / den;
             const float gd = -(sm * (my_w - wbar)) * inv_t;                    // d loss_t / d d_s
@@ -440,7 +441,11 @@ __global__ __launch_bounds__(TPB) void hyphc_kernel(const float* __restrict__ xn
     }
     const double tot = hpcs_block_sum<double>(acc, red);
     if (threadIdx.x == 0 && tot != 0.0) atomicAdd(BWD ? gscale : loss_sum, tot);
-    if (!BWD && kept_out) {
+    if (BWD && loss_sum) {                 // one-pass mode: the loss itself comes out of the gradient pass
+        const double lt = hpcs_block_sum<double>(acc_loss, red);
+        if (threadIdx.x == 0 && lt != 0.0) atomicAdd(loss_sum, lt);
+    }
+    if (kept_out) {
         const double kt = hpcs_block_sum<double>((double)kept, red);
         if (threadIdx.x == 0 && kt != 0.0) atomicAdd(kept_out, (unsigned long long)kt);
     }
@@ -753,13 +758,15 @@ extern "C" int hpcs_hyphc_fwd(const float* xn, int E, const int64_t* a, const in
 extern "C" int hpcs_hyphc_bwd(const float* xn, int E, const int64_t* a, const int64_t* p, const int64_t* n,
                               const int64_t* count, int64_t T_cap, const float* scale, float temperature, float margin,
                               int kind, const int64_t* norm_count, const float* gloss, float* gxn, double* gscale,
-                              hpcs_stream_t stream) {
+                              double* loss_sum, int64_t* kept, hpcs_stream_t stream) {
     if (!xn || !a || !p || !n || !count || !scale || !gloss || !gxn || !gscale) return HPCS_ERR_NULL;
     if (E <= 0 || T_cap < 0 || !(temperature > 0.f) || kind > 3 || (kind >= 0 && !norm_count)) return HPCS_ERR_SHAPE;
     if (hipMemsetAsync(gscale, 0, sizeof(double), ST) != hipSuccess) return HPCS_ERR_HIP;
+    if (loss_sum && hipMemsetAsync(loss_sum, 0, sizeof(double), ST) != hipSuccess) return HPCS_ERR_HIP;
+    if (kept && hipMemsetAsync(kept, 0, sizeof(int64_t), ST) != hipSuccess) return HPCS_ERR_HIP;
     if (T_cap == 0) return HPCS_OK;
-    const int rc = launch_hyphc<true>(xn, E, a, p, n, count, T_cap, scale, temperature, margin, kind, norm_count, nullptr,
-                                      gloss, nullptr, gxn, gscale, ST);
+    const int rc = launch_hyphc<true>(xn, E, a, p, n, count, T_cap, scale, temperature, margin, kind, norm_count,
+                                      (unsigned long long*)kept, gloss, loss_sum, gxn, gscale, ST);
     if (rc) return rc;
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;

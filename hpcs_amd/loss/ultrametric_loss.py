@@ -53,6 +53,8 @@ class HypHCFn(torch.autograd.Function):
 
     kind=None: (a,p,n,count) are already mined.  kind in {"all","easy","semihard","hard"}: (a,p,n) are the sampled
     triplets and the miner's margin rule is evaluated inside the loss kernels (no compaction pass).
+    When a gradient is needed the forward runs the gradient kernel in one-pass mode (loss + kept count + unscaled
+    gradient in a single sweep over the triplets); backward only rescales by upstream/kept.
     """
 
     @staticmethod
@@ -61,31 +63,41 @@ class HypHCFn(torch.autograd.Function):
         dev = xn.device
         loss_sum = torch.empty(1, dtype=torch.float64, device=dev)
         kid = _KIND[kind]
-        kept = torch.empty(1, dtype=torch.int64, device=dev) if kid >= 0 else None
-        call("hpcs_hyphc_fwd", xn, E, a, p, n, count, a.numel(), scale, temperature, margin, kid, loss_sum, kept)
-        norm = kept if kid >= 0 else count
+        kept = torch.empty(1, dtype=torch.int64, device=dev)
+        need_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        gxn_raw = gscale_raw = None
+        if need_grad:
+            ones_f = torch.ones(1, device=dev)
+            ones_i = torch.ones(1, dtype=torch.int64, device=dev)
+            gxn_raw = torch.zeros(M, E, device=dev)
+            gscale_raw = torch.empty(1, dtype=torch.float64, device=dev)
+            call("hpcs_hyphc_bwd", xn, E, a, p, n, count, a.numel(), scale, temperature, margin, kid, ones_i, ones_f,
+                 gxn_raw, gscale_raw, loss_sum, kept)
+        else:
+            call("hpcs_hyphc_fwd", xn, E, a, p, n, count, a.numel(), scale, temperature, margin, kid, loss_sum,
+                 kept if kid >= 0 else None)
+        norm = kept if (kid >= 0 or need_grad) else count
+        if kid < 0 and need_grad:
+            norm = count                       # pre-mined triplets: the mean is over `count`
         _LAST_KEPT[0] = norm
         colsum = torch.empty(E, dtype=torch.float64, device=dev)
         call("hpcs_colsum", xn, M, E, colsum)
         mean_sim = 0.5 + 0.5 * (colsum * colsum).sum() / float(M * M)
         out = loss_sum[0] / norm[0].double() + mean_sim
-        ctx.save_for_backward(xn, scale, a, p, n, count, colsum, norm)
-        ctx.cfg = (temperature, margin, kid)
-        ctx.kept = norm
+        ctx.save_for_backward(scale, colsum, norm, gxn_raw, gscale_raw)
+        ctx.M = M
         return out.float()
 
     @staticmethod
     def backward(ctx, g):
-        xn, scale, a, p, n, count, colsum, norm = ctx.saved_tensors
-        temperature, margin, kid = ctx.cfg
-        M, E = xn.shape
-        g32 = g.reshape(1).contiguous().float()
+        scale, colsum, norm, gxn_raw, gscale_raw = ctx.saved_tensors
+        M = ctx.M
+        g32 = g.reshape(1).float()
+        inv = (g32.double() / norm.double().clamp_min(1)).float()          # upstream / kept
         # d mean_sim / d xn_i = colsum / M^2 (same row for every i)
-        gxn = ((colsum / float(M * M)).float() * g32).unsqueeze(0).repeat(M, 1).contiguous()
-        gscale = torch.empty(1, dtype=torch.float64, device=xn.device)
-        call("hpcs_hyphc_bwd", xn, E, a, p, n, count, a.numel(), scale, temperature, margin, kid,
-             norm if kid >= 0 else None, g32, gxn, gscale)
-        return gxn, gscale.float().view_as(scale), None, None, None, None, None, None, None
+        gxn = torch.addcmul((colsum / float(M * M)).float().mul(g32).unsqueeze(0), gxn_raw, inv)
+        gscale = (gscale_raw * inv.double()).float().view_as(scale)
+        return gxn, gscale, None, None, None, None, None, None, None
 
 
 class CosFaceFn(torch.autograd.Function):

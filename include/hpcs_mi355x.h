@@ -219,10 +219,13 @@ int hpcs_triplet_filter(const float* xn, int E, const int64_t* a, const int64_t*
 int hpcs_hyphc_fwd(const float* xn, int E, const int64_t* a, const int64_t* p, const int64_t* n,
                    const int64_t* count, int64_t T_cap, const float* scale, float temperature, float margin,
                    int kind, double* loss_sum, int64_t* kept, hpcs_stream_t stream);
+/* bwd with loss_sum/kept != NULL is the ONE-PASS mode used in training: called from the forward with *gloss = 1 and
+ * *norm_count = 1 it returns the loss sum, the kept count and the UNSCALED gradient in a single sweep over the
+ * triplets (the loss is linear in its upstream gradient, so backward is a rescale by gloss/kept). */
 int hpcs_hyphc_bwd(const float* xn, int E, const int64_t* a, const int64_t* p, const int64_t* n,
                    const int64_t* count, int64_t T_cap, const float* scale, float temperature, float margin,
                    int kind, const int64_t* norm_count, const float* gloss, float* gxn, double* gscale,
-                   hpcs_stream_t stream);
+                   double* loss_sum, int64_t* kept, hpcs_stream_t stream);
 /* mean of the M x M similarity in closed form: 0.5 + 0.5*|sum_i xn_i|^2/M^2.  colsum [E] double. */
 int hpcs_colsum(const float* xn, int64_t rows, int E, double* colsum, hpcs_stream_t stream);
 /* cosface: plain CosFace = one level of singleton branches (branch_id NULL, n_levels 1).  Hierarchical CosFace
