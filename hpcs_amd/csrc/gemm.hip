@@ -266,6 +266,30 @@ NtPlan nt_plan(int M, int Kx, int Nc, int n_batch) {
     return p;
 }
 
+// One launch builds both GEMM operands of a (stacked) weight matrix W = [W1; W2] (rows M1 + M2, K columns):
+//   At [K][lda]  = W^T, zero padded to lda = pad4(M)   (forward:  C = At^T X)
+//   Wp [M][ldp]  = W,   zero padded to ldp = pad4(K)   (data-grad: gX = Wp^T G)
+__global__ void prep_weights_kernel(const float* __restrict__ W1, int ld1, int M1, const float* __restrict__ W2, int ld2,
+                                    int M2, int K, float* __restrict__ At, int lda, float* __restrict__ Wp, int ldp) {
+    const int M = M1 + M2;
+    const int64_t nA = (int64_t)K * lda, nP = (int64_t)M * ldp;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nA + nP; e += (int64_t)gridDim.x * blockDim.x) {
+        if (e < nA) {
+            const int k = (int)(e / lda), m = (int)(e % lda);
+            float v = 0.f;
+            if (m < M1) v = W1[(int64_t)m * ld1 + k];
+            else if (m < M) v = W2[(int64_t)(m - M1) * ld2 + k];
+            At[e] = v;
+        } else {
+            const int64_t q = e - nA;
+            const int m = (int)(q / ldp), k = (int)(q % ldp);
+            float v = 0.f;
+            if (k < K) v = m < M1 ? W1[(int64_t)m * ld1 + k] : W2[(int64_t)(m - M1) * ld2 + k];
+            Wp[q] = v;
+        }
+    }
+}
+
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
 
 }  // namespace
@@ -333,6 +357,19 @@ extern "C" int hpcs_gemm_nt(const float* G, int ldg, int64_t strideG_o, int64_t 
     const int64_t ne = (int64_t)M * Kx;
     hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)hpcs_cdiv(ne, 64)), dim3(1024), 0, st, (const float*)ws,
                        p.nsplit, M, Kx, dW, lddw, accumulate);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
+extern "C" int hpcs_prep_weights(const float* W1, int ld1, int M1, const float* W2, int ld2, int M2, int K, float* At, int lda,
+                                 float* Wp, int ldp, hpcs_stream_t stream) {
+    if (!W1 || !At || !Wp || (M2 > 0 && !W2)) return HPCS_ERR_NULL;
+    if (M1 <= 0 || M2 < 0 || K <= 0 || ld1 < K || (M2 > 0 && ld2 < K) || lda < M1 + M2 || ldp < K) return HPCS_ERR_SHAPE;
+    const int64_t n = (int64_t)K * lda + (int64_t)(M1 + M2) * ldp;
+    int blocks = hpcs_cdiv(n, 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(prep_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, W1, ld1, M1, W2, ld2, M2, K, At, lda,
+                       Wp, ldp);
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;
 }

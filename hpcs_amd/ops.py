@@ -26,43 +26,49 @@ def _pad4(n):
     return (n + 3) // 4 * 4
 
 
-def _as_At(W):
-    """[M,K] weights -> K-major operand [K, pad4(M)] for hpcs_gemm_tn (computes W @ X)."""
-    M, K = W.shape
-    At = torch.zeros(K, _pad4(M), device=W.device, dtype=torch.float32)
-    At[:, :M] = W.t()
-    return At
-
-
-def _pad_cols(W):
-    """[M,K] -> [M, pad4(K)] (operand of the data-grad GEMM W^T @ G)."""
-    M, K = W.shape
-    if K % 4 == 0:
-        return W.contiguous()
-    P = torch.zeros(M, _pad4(K), device=W.device, dtype=torch.float32)
-    P[:, :K] = W
-    return P
-
-
 # ------------------------------------------------------------------------------------------------ raw GEMMs
+class PreparedW:
+    """GEMM operands of W = [W1; W2] built by ONE kernel: At = W^T [K, pad4(M)] and Wp = W [M, pad4(K)]."""
+    __slots__ = ("At", "Wp", "M", "K")
+
+    def __init__(self, W1, W2=None):
+        _need_cuda(W1, W2)
+        if W1.stride(-1) != 1 or (W2 is not None and W2.stride(-1) != 1):
+            W1 = W1.contiguous()
+            W2 = None if W2 is None else W2.contiguous()
+        W1 = W1 if W1.dtype == torch.float32 else W1.float()
+        M1, K = W1.shape
+        M2 = 0 if W2 is None else W2.shape[0]
+        M = M1 + M2
+        self.M, self.K = M, K
+        self.At = torch.empty(K, _pad4(M), device=W1.device, dtype=torch.float32)
+        self.Wp = torch.empty(M, _pad4(K), device=W1.device, dtype=torch.float32)
+        call("hpcs_prep_weights", W1.data_ptr(), W1.stride(0), M1, None if W2 is None else W2.data_ptr(),
+             0 if W2 is None else W2.stride(0), M2, K, self.At, self.At.shape[1], self.Wp, self.Wp.shape[1])
+
+
+def _prep(W):
+    return W if isinstance(W, PreparedW) else PreparedW(W)
+
+
 def gemm_WX(W, X, nb, K, Nc, rowbias=None, out=None, accumulate=False):
     """out[b] (M x Nc) = W (M x K) @ X[b] (K x Nc); X / out are [nb, K, Nc] / [nb, M, Nc] views of contiguous data."""
-    M = W.shape[0]
+    W = _prep(W)
+    M = W.M
     if out is None:
         out = torch.empty(nb * M * Nc, device=X.device, dtype=torch.float32)
-    At = _as_At(W)
-    call("hpcs_gemm_tn", At, At.shape[1], X, Nc, K * Nc, 0, out, Nc, M * Nc, 0, M, Nc, K, nb, 1, rowbias,
+    call("hpcs_gemm_tn", W.At, W.At.shape[1], X, Nc, K * Nc, 0, out, Nc, M * Nc, 0, M, Nc, K, nb, 1, rowbias,
          1 if accumulate else 0)
     return out
 
 
 def gemm_WtG(W, G, nb, M, Nc, out=None, accumulate=False):
     """out[b] (K x Nc) = W^T (K x M) @ G[b] (M x Nc)."""
-    K = W.shape[1]
+    W = _prep(W)
+    K = W.K
     if out is None:
         out = torch.empty(nb * K * Nc, device=G.device, dtype=torch.float32)
-    Wp = _pad_cols(W)
-    call("hpcs_gemm_tn", Wp, Wp.shape[1], G, Nc, M * Nc, 0, out, Nc, K * Nc, 0, K, Nc, M, nb, 1, None,
+    call("hpcs_gemm_tn", W.Wp, W.Wp.shape[1], G, Nc, M * Nc, 0, out, Nc, K * Nc, 0, K, Nc, M, nb, 1, None,
          1 if accumulate else 0)
     return out
 
@@ -128,21 +134,25 @@ class ChanMixFn(torch.autograd.Function):
         Nc = x[0, 0].numel()
         M = W.shape[0]
         rb = _f32c(rowbias) if rowbias is not None else None
-        y = gemm_WX(W, x, B, K, Nc, rowbias=rb).view(B, M, *x.shape[2:])
-        ctx.save_for_backward(x, W)
+        Wq = PreparedW(W)
+        y = gemm_WX(Wq, x, B, K, Nc, rowbias=rb).view(B, M, *x.shape[2:])
+        ctx.save_for_backward(x, Wq.Wp)
+        ctx.mk = (M, K)
         ctx.has_bias = rowbias is not None
         return y
 
     @staticmethod
     def backward(ctx, g):
-        x, W = ctx.saved_tensors
+        x, Wp = ctx.saved_tensors
         g = _f32c(g)
-        B, K = x.shape[0], x.shape[1]
+        B = x.shape[0]
         Nc = x[0, 0].numel()
-        M = W.shape[0]
+        M, K = ctx.mk
         gx = gW = gb = None
         if ctx.needs_input_grad[0]:
-            gx = gemm_WtG(W, g, B, M, Nc).view_as(x)
+            gx = torch.empty(B * K * Nc, device=g.device)
+            call("hpcs_gemm_tn", Wp, Wp.shape[1], g, Nc, M * Nc, 0, gx, Nc, K * Nc, 0, K, Nc, M, B, 1, None, 0)
+            gx = gx.view_as(x)
         if ctx.needs_input_grad[1]:
             gW = gemm_GXt(g, x, B, M, K, Nc)
         if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -159,10 +169,10 @@ def chan_mix(x, W, rowbias=None):
 # ------------------------------------------------------------------------------------------------ a3
 def _gemm_inner3(W, x, B, K, L, rowbias3):
     """PD[b,:,a,:] = W @ x[b,:,a,:] + rowbias3[b,a,:]  -- walks a [B,K,3,L] tensor as 3B matrices of L columns."""
-    M = W.shape[0]
+    W = _prep(W)
+    M = W.M
     out = torch.empty(B * M * 3 * L, device=x.device, dtype=torch.float32)
-    At = _as_At(W)
-    call("hpcs_gemm_tn", At, At.shape[1], x, 3 * L, K * 3 * L, L, out, 3 * L, M * 3 * L, L, M, L, K, B, 3, rowbias3, 0)
+    call("hpcs_gemm_tn", W.At, W.At.shape[1], x, 3 * L, K * 3 * L, L, out, 3 * L, M * 3 * L, L, M, L, K, B, 3, rowbias3, 0)
     return out
 
 
@@ -182,20 +192,22 @@ class VNLayerFn(torch.autograd.Function):
         L = x[0, 0, 0].numel()
         Cout = Wf.shape[0]
         Cd = Wd.shape[0] if (Wd is not None and (flags & VN_LRELU)) else 0
-        Wcat = torch.cat([Wf, Wd], 0) if Cd else Wf
-        Wcat = _f32c(Wcat)
+        Wd_ = Wd if Cd else None
         Ctot = Cout + Cd
         Cc = 0
+        WcP = None
         if xconst is not None:
             xconst = _f32c(xconst)
             Cc = xconst.shape[1]
-            Wx = Wcat[:, :Cin].contiguous()
-            Wc = Wcat[:, Cin:].contiguous()
-            bias = gemm_WX(Wc, xconst, B, Cc, 3).view(B, Ctot, 3).permute(0, 2, 1).contiguous()     # [B,3,Ctot]
-            PD = _gemm_inner3(Wx, x, B, Cin, L, bias)
+            WxP = PreparedW(Wf[:, :Cin], None if Wd_ is None else Wd_[:, :Cin])      # column slices: no copies
+            WcP = PreparedW(Wf[:, Cin:], None if Wd_ is None else Wd_[:, Cin:])
+            bias = gemm_WX(WcP, xconst, B, Cc, 3).view(B, Ctot, 3).permute(0, 2, 1).contiguous()     # [B,3,Ctot]
+            PD = _gemm_inner3(WxP, x, B, Cin, L, bias)
         else:
-            Wx, Wc = Wcat, None
-            PD = gemm_WX(Wcat, x, B, Cin, 3 * L)
+            WxP = PreparedW(Wf, Wd_)
+            PD = gemm_WX(WxP, x, B, Cin, 3 * L)
+        Wx = WxP.Wp
+        Wc = None if WcP is None else WcP.Wp
         dev = x.device
         mean = rstd = None
         if flags & VN_BN:
@@ -231,13 +243,18 @@ class VNLayerFn(torch.autograd.Function):
              flags, GPD)
         gx = gW = gWd = ggamma = gbeta = gxc = None
         if ctx.needs_input_grad[0]:
-            gx = gemm_WtG(Wx, GPD, B, Ctot, 3 * L).view_as(x)
+            gx = torch.empty(B * Cin * 3 * L, device=dev)
+            call("hpcs_gemm_tn", Wx, Wx.shape[1], GPD, 3 * L, Ctot * 3 * L, 0, gx, 3 * L, Cin * 3 * L, 0, Cin, 3 * L, Ctot, B, 1,
+                 None, 0)
+            gx = gx.view_as(x)
         S = None
         if Cc:
             S = torch.empty(B, Ctot, 3, device=dev)
             call("hpcs_rowsum", GPD, B * Ctot * 3, L, 1.0, S)
             if ctx.needs_input_grad[11]:
-                gxc = gemm_WtG(Wc, S, B, Ctot, 3).view(B, Cc, 3)
+                gxc = torch.empty(B * Cc * 3, device=dev)
+                call("hpcs_gemm_tn", Wc, Wc.shape[1], S, 3, Ctot * 3, 0, gxc, 3, Cc * 3, 0, Cc, 3, Ctot, B, 1, None, 0)
+                gxc = gxc.view(B, Cc, 3)
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             gWcat = gemm_GXt(GPD, x, B, Ctot, Cin, 3 * L)
             if Cc:

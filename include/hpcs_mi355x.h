@@ -68,6 +68,10 @@ int hpcs_edge_gather_bwd(const float* gout, const int64_t* idx, int B, int C, in
 int hpcs_gemm_tn(const float* At, int lda, const float* Bm, int ldb, int64_t strideB_o, int64_t strideB_i,
                  float* C, int ldc, int64_t strideC_o, int64_t strideC_i, int M, int Nc, int K, int n_outer,
                  int n_inner, const float* rowbias, int accumulate, hpcs_stream_t stream);
+/* prep_weights: W = [W1 (M1 x K, row stride ld1); W2 (M2 x K, row stride ld2, optional)] -> both GEMM operands in one
+ * launch: At [K, lda >= M] = W^T and Wp [M, ldp >= K] = W, zero padded (lda, ldp multiples of 4 for 16-byte loads). */
+int hpcs_prep_weights(const float* W1, int ld1, int M1, const float* W2, int ld2, int M2, int K, float* At, int lda,
+                      float* Wp, int ldp, hpcs_stream_t stream);
 size_t hpcs_gemm_nt_workspace(int M, int Kx, int Nc, int n_outer, int n_inner);
 int hpcs_gemm_nt(const float* G, int ldg, int64_t strideG_o, int64_t strideG_i, const float* X, int ldx,
                  int64_t strideX_o, int64_t strideX_i, int M, int Kx, int Nc, int n_outer, int n_inner, float* dW,
