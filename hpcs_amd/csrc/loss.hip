@@ -550,12 +550,14 @@ __device__ __forceinline__ float dlogit(const float* __restrict__ lr, float lse,
     return d;
 }
 
-// grad wrt xn rows; one thread per row
+// grad wrt xn rows; one thread per row.  The row's d(logit) vector is staged once in LDS ([row][C+1], conflict-free
+// for the per-thread walk) so exp() is evaluated C times per row, not C*E times.
 __global__ void cosface_bwd_x_kernel(const float* __restrict__ wn, const int64_t* __restrict__ labels,
                                      const float* __restrict__ logits, const float* __restrict__ lse_rows,
                                      const int32_t* __restrict__ bid, int n_levels, int M, int E, int C, float scale,
                                      const float* __restrict__ gloss, float* __restrict__ gxn) {
-    extern __shared__ float wsh[];
+    extern __shared__ float wsh[];               // [C][E] weights, then [blockDim][C+1] d(logit)
+    float* dl = wsh + C * E + threadIdx.x * (C + 1);
     const float gmean = *gloss / (float)M;
     for (int i = threadIdx.x; i < C * E; i += blockDim.x) wsh[i] = wn[i];
     __syncthreads();
@@ -566,10 +568,10 @@ __global__ void cosface_bwd_x_kernel(const float* __restrict__ wn, const int64_t
     const float lse = lse_rows[row];
     float S[MAX_LEVELS];
     branch_mass(lr, lse, bid, n_levels, C, lab, S);
+    for (int c = 0; c < C; ++c) dl[c] = dlogit(lr, lse, bid, n_levels, C, lab, c, S) * gmean * scale;
     for (int e = 0; e < E; ++e) {
         float acc = 0.f;
-        for (int c = 0; c < C; ++c)
-            acc = __builtin_fmaf(dlogit(lr, lse, bid, n_levels, C, lab, c, S) * gmean * scale, wsh[c * E + e], acc);
+        for (int c = 0; c < C; ++c) acc = __builtin_fmaf(dl[c], wsh[c * E + e], acc);
         gxn[(int64_t)row * E + e] += acc;
     }
 }
@@ -793,8 +795,8 @@ extern "C" int hpcs_cosface_bwd(const float* xn, const float* wn, const int64_t*
     if (n_levels < 1 || n_levels > MAX_LEVELS || (n_levels > 1 && !branch_id)) return HPCS_ERR_SHAPE;
     if (hipMemsetAsync(gwn, 0, sizeof(float) * C * E, ST) != hipSuccess) return HPCS_ERR_HIP;
     if (M == 0) return HPCS_OK;
-    hipLaunchKernelGGL(cosface_bwd_x_kernel, dim3(hpcs_cdiv(M, 64)), dim3(64), (size_t)C * E * 4, ST, wn, labels, logits,
-                       lse_rows, branch_id, n_levels, M, E, C, scale, gloss, gxn);
+    hipLaunchKernelGGL(cosface_bwd_x_kernel, dim3(hpcs_cdiv(M, 64)), dim3(64), ((size_t)C * E + 64 * (C + 1)) * 4, ST, wn, labels,
+                       logits, lse_rows, branch_id, n_levels, M, E, C, scale, gloss, gxn);
     HPCS_CHECK_LAUNCH();
     int rpb = (48 * 1024) / (4 * C);
     if (rpb > 256) rpb = 256;
