@@ -51,10 +51,16 @@ def build_step(args, device):
     from hpcs_amd.step import HypHCStep
     torch.manual_seed(0)
     feat = VN_DGCNN_partseg(in_channels=3, out_features=args.embedding, k=args.k, dropout=0.5, pooling="mean",
-                            num_categories=16)
-    step = HypHCStep(feat, ExpMap(), hyp_size=args.embedding, num_class=args.num_class, num_categories=16, lr=0.05,
-                     margin=0.35, t_per_anchor=50, fraction=1.2, temperature=0.05, trade_off=0.1, miner=True,
-                     cosface=True, train_rotation="so3", rng="device")
+                            num_categories=args.num_categories)
+    hier = None
+    if args.hierarchical:          # synthetic 3-level part hierarchy: groups of 8, groups of 3, leaves
+        C = args.num_class
+        hier = [[list(range(i, min(i + 8, C))) for i in range(0, C, 8)],
+                [list(range(i, min(i + 3, C))) for i in range(0, C, 3)], [[c] for c in range(C)]]
+    step = HypHCStep(feat, ExpMap(), hyp_size=args.embedding, num_class=args.num_class,
+                     num_categories=args.num_categories, lr=0.05, margin=0.35, t_per_anchor=50, fraction=1.2,
+                     temperature=0.05, trade_off=0.1, miner=True, cosface=True, train_rotation="so3", rng="device",
+                     hierarchical=args.hierarchical, hierarchy_list=hier)
     step.to(device).train()
     return step.configure()
 
@@ -151,6 +157,8 @@ def main():
     ap.add_argument("--k", type=int, default=20)
     ap.add_argument("--embedding", type=int, default=32)
     ap.add_argument("--num-class", type=int, default=50)
+    ap.add_argument("--num-categories", type=int, default=16)
+    ap.add_argument("--hierarchical", action="store_true", help="PartNet-style hierarchical CosFace (cfg-3/5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -174,7 +182,7 @@ def main():
 
     step = build_step(args, device)
     broadcast_parameters(step)
-    pts, cat, tgt = synthetic_batch(args.batch, args.points, args.num_class, 16, seed=rank)
+    pts, cat, tgt = synthetic_batch(args.batch, args.points, args.num_class, args.num_categories, seed=rank)
     pts_d, cat_d, tgt_d = pts.to(device), cat.to(device), tgt.to(device)
 
     def barrier():

@@ -10,7 +10,7 @@ module is the minimal stand-in that the benchmark, the smoke test and the data-p
 import torch
 
 from .dp import FlatGradBucket
-from .loss.ultrametric_loss import MetricHyperbolicLoss
+from .loss.ultrametric_loss import HierarchicalMetricHyperbolicLoss, MetricHyperbolicLoss
 from .optim import RAdam
 
 
@@ -34,7 +34,7 @@ def to_categorical(y, num_classes):
 class HypHCStep(torch.nn.Module):
     def __init__(self, nn_feat, nn_emb, hyp_size, num_class, num_categories=16, lr=1e-3, margin=0.5, t_per_anchor=50,
                  fraction=1.2, temperature=0.05, anneal_factor=0.5, trade_off=0.1, miner=True, cosface=True,
-                 train_rotation="so3", rng="device", fused_filter=True):
+                 train_rotation="so3", rng="device", fused_filter=True, hierarchical=False, hierarchy_list=None):
         super().__init__()
         self.nn_feat = nn_feat
         self.nn_emb = nn_emb
@@ -42,11 +42,13 @@ class HypHCStep(torch.nn.Module):
         self.trade_off = trade_off
         self.train_rotation = train_rotation
         self.scale = torch.nn.Parameter(torch.Tensor([1e-3]), requires_grad=True)        # base_hyp_hc.py:62
-        self.metric_hyp_loss = MetricHyperbolicLoss(margin=margin, t_per_anchor=t_per_anchor, fraction=fraction,
-                                                    scale=self.scale, temperature=temperature,
-                                                    anneal_factor=anneal_factor, num_class=num_class,
-                                                    embedding_size=hyp_size, miner=miner, cosface=cosface, rng=rng,
-                                                    fused_filter=fused_filter)
+        common = dict(margin=margin, t_per_anchor=t_per_anchor, fraction=fraction, scale=self.scale,
+                      temperature=temperature, anneal_factor=anneal_factor, num_class=num_class, embedding_size=hyp_size,
+                      miner=miner, rng=rng, fused_filter=fused_filter)
+        if hierarchical:                       # PartNet default (partnet_hyp_hc.py:57-67)
+            self.metric_hyp_loss = HierarchicalMetricHyperbolicLoss(hierarchy_list=hierarchy_list, **common)
+        else:
+            self.metric_hyp_loss = MetricHyperbolicLoss(cosface=cosface, **common)
         self.lr = lr
         self.optimizer = None
         self.bucket = None
