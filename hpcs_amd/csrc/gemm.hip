@@ -29,7 +29,7 @@ __device__ __forceinline__ float4 ld4_guard(const float* __restrict__ rowp, int 
 }
 
 template <int BM, int BN, int BK, int WM, int WN>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_tn_kernel(
+__global__ __launch_bounds__(WM* WN * 64, 4) void gemm_tn_kernel(
     const float* __restrict__ At, int lda, const float* __restrict__ Bm, int ldb, int64_t sBo, int64_t sBi,
     float* __restrict__ C, int ldc, int64_t sCo, int64_t sCi, int M, int Nc, int K, int n_inner,
     const float* __restrict__ rowbias, int accumulate, int tilesM, int tilesN, unsigned total, int vecA,
