@@ -451,6 +451,208 @@ __global__ __launch_bounds__(TPB) void hyphc_kernel(const float* __restrict__ xn
     }
 }
 
+// ---------------------------------------------------------------------------------------------- HypHC, sampled in place
+// Training-path kernel for rng = "device": the class-balanced triplets are GENERATED inside the loss kernel from the
+// counter RNG (no 3 x T int64 index arrays, no sampler / filter passes), the miner's margin rule is applied inline,
+// and loss, kept count and the unscaled gradient come out of one sweep.
+//   triplet t -> class c (cls_toff), anchor rank = (t - toff_c) / k_c, positive = uniform over the class minus the
+//   anchor, negative = uniform over the other classes by rejection on the label (identical distribution to the
+//   reference's "index into the list of non-members", loss_and_miner_utils.py:61-62).
+// Work layout: a 1024-thread workgroup owns TB consecutive triplets (class-major order, so almost always one class);
+// each 8-lane group walks SEG consecutive triplets (one anchor for long stretches: its gradient lives in registers).
+// Positive rows belong to the anchor's class: their gradients accumulate in an LDS table indexed by the member's
+// rank (ds_add_f32) and are flushed once per workgroup -- ~10x fewer global atomics than one per triplet; negative
+// rows are random over the cloud and use the row-contiguous global atomic shape.
+constexpr int SB_THREADS = 1024;
+constexpr int SB_GROUPS = SB_THREADS / SUB;      // 128
+constexpr int SB_SEG = 128;                      // triplets per 8-lane group
+constexpr int SB_TB = SB_GROUPS * SB_SEG;        // 16384 triplets per workgroup
+
+__device__ __forceinline__ int class_of(const int64_t* __restrict__ toff, int C, int64_t t) {
+    int lo = 0, hi = C;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (toff[mid] <= t) lo = mid; else hi = mid;
+    }
+    while (lo + 1 < C && toff[lo + 1] <= t) ++lo;
+    return lo;
+}
+
+template <int EPL, bool GRAD>
+__global__ __launch_bounds__(SB_THREADS) void hyphc_sampled_kernel(
+    const float* __restrict__ xn, const int64_t* __restrict__ labels, const int32_t* __restrict__ order,
+    const int32_t* __restrict__ offsets, const int64_t* __restrict__ cls_toff, const int32_t* __restrict__ cls_k, int C,
+    int M, int64_t T, uint64_t seed, const float* __restrict__ scale, float temperature, float margin, int kind, int RC,
+    double* __restrict__ loss_sum, unsigned long long* __restrict__ kept_out, float* __restrict__ gxn,
+    double* __restrict__ gscale, int64_t* __restrict__ a_dbg, int64_t* __restrict__ p_dbg, int64_t* __restrict__ n_dbg,
+    unsigned perm_mul) {
+    constexpr int E = 8 * EPL;
+    using IO = RowIO<EPL, true>;
+    constexpr int LD = E + 8;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* cache = smem;                                            // [RC][E]   (GRAD only)
+    float* stage = smem + (GRAD ? (size_t)RC * E : 0);              // [waves][8][LD] negative-row transposition slab
+    __shared__ double red[16];
+    __shared__ int cb_sh[3];
+
+    const float sraw = *scale;
+    const float sc = fminf(fmaxf(sraw, 1e-4f), 1.f);
+    const bool s_live = sraw >= 1e-4f && sraw <= 1.f;
+    const float inv_t = 1.f / temperature;
+    const int lane = threadIdx.x & 63;
+    const int s = threadIdx.x % SUB, g = threadIdx.x / SUB;
+    const int sub0 = lane & ~(SUB - 1);
+    const unsigned pblock = (unsigned)(((uint64_t)blockIdx.x * perm_mul) % gridDim.x);
+    const int64_t block_base = (int64_t)pblock * SB_TB;
+
+    if (threadIdx.x == 0) {
+        const int cb = class_of(cls_toff, C, block_base < T ? block_base : T - 1);
+        cb_sh[0] = cb;
+        cb_sh[1] = offsets[cb];
+        cb_sh[2] = offsets[cb + 1] - offsets[cb];
+    }
+    if (GRAD)
+        for (int i = threadIdx.x; i < RC * E; i += SB_THREADS) cache[i] = 0.f;
+    __syncthreads();
+    const int cb = cb_sh[0];
+
+    const int64_t seg = block_base + (int64_t)g * SB_SEG;
+    int c = class_of(cls_toff, C, seg < T ? seg : T - 1);
+    double acc_loss = 0.0, acc_gs = 0.0;
+    unsigned kept = 0;
+    float acc_a[EPL];
+    int64_t cur = -1;
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) acc_a[j] = 0.f;
+
+    for (int i = 0; i < SB_SEG; ++i) {
+        const int64_t t = seg + i;
+        bool live = t < T;
+        const int64_t tt = live ? t : T - 1;
+        while (c + 1 < C && cls_toff[c + 1] <= tt) ++c;
+        const int k = cls_k[c];
+        const int off = offsets[c];
+        const int n_a = offsets[c + 1] - off;
+        const int rank = (int)((tt - cls_toff[c]) / (k > 0 ? k : 1));
+        const int64_t ia = order[off + rank];
+        const int64_t rp = (int64_t)bounded(mix64(seed ^ mix64(2 * (uint64_t)tt)), (uint64_t)(n_a > 1 ? n_a - 1 : 1));
+        const int pr = (int)(rp + (rp >= rank ? 1 : 0));
+        const int64_t ip = order[off + (pr < n_a ? pr : 0)];
+        int64_t in;
+        {   // negative: uniform over points of other classes (rejection on the label; expected 1/(1 - n_a/M) draws)
+            uint64_t h = mix64(seed ^ mix64(2 * (uint64_t)tt + 1));
+            in = (int64_t)bounded(h, (uint64_t)M);
+            int guard = 0;
+            while (labels[in] == c && guard < 64) {
+                h = mix64(h + 0x632BE59BD9B4E019ull);
+                in = (int64_t)bounded(h, (uint64_t)M);
+                ++guard;
+            }
+        }
+        if (a_dbg && live && s == 0) { a_dbg[t] = ia; p_dbg[t] = ip; n_dbg[t] = in; }
+
+        float av[EPL], pv[EPL], nv[EPL];
+        IO::load(xn, E, ia, s, av);
+        IO::load(xn, E, ip, s, pv);
+        IO::load(xn, E, in, s, nv);
+        float d1 = 0.f, d2 = 0.f, d3 = 0.f;
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+            d1 += av[j] * pv[j];
+            d2 += av[j] * nv[j];
+            d3 += pv[j] * nv[j];
+        }
+        d1 = sub_sum(d1);
+        d2 = sub_sum(d2);
+        d3 = sub_sum(d3);
+        if (kind >= 0) {
+            const float tm = 0.5f * (1.f + d1) - 0.5f * (1.f + d2);
+            live = live && keep_rule(tm, margin, kind);
+        }
+        if (live && s == 0) ++kept;
+        const float my_dot = s == 0 ? d1 : (s == 1 ? d2 : d3);
+        const LcaF L = lca_of_dot(sc, my_dot);
+        const float dsc = L.d * inv_t;
+        const float q0 = __shfl(dsc, sub0, 64), q1 = __shfl(dsc, sub0 + 1, 64), q2 = __shfl(dsc, sub0 + 2, 64);
+        const float mx = fmaxf(q0, fmaxf(q1, q2));
+        const float ex = __expf(dsc - mx);
+        const float e0 = __shfl(ex, sub0, 64), e1 = __shfl(ex, sub0 + 1, 64), e2 = __shfl(ex, sub0 + 2, 64);
+        const float w0 = 0.5f * (1.f + d1), w1 = 0.5f * (1.f + d2), w2 = 0.5f * (1.f + d3);
+        const float den = e0 + e1 + e2;
+        const float wbar = (e0 * w0 + e1 * w1 + e2 * w2) / den;
+        if (live && s == 0) acc_loss += (double)((w0 + w1 + w2) - wbar);
+        if (GRAD) {
+            const float my_w = s == 0 ? w0 : (s == 1 ? w1 : w2);
+            const float sm = ex / den;
+            const float gd = -(sm * (my_w - wbar)) * inv_t;
+            const float gw = (1.f - sm) + gd * L.dd_dw;                      // unscaled: upstream/kept applied later
+            if (live && s < 3 && s_live) acc_gs += (double)(gd * L.dd_ds);
+            const float c0 = 0.5f * __shfl(gw, sub0, 64), c1 = 0.5f * __shfl(gw, sub0 + 1, 64),
+                        c2 = 0.5f * __shfl(gw, sub0 + 2, 64);
+            if (live) {
+                if (ia != cur) {
+                    if (cur >= 0) {
+#pragma unroll
+                        for (int j = 0; j < EPL; ++j) atomicAdd(gxn + cur * E + s * EPL + j, acc_a[j]);
+                    }
+                    cur = ia;
+#pragma unroll
+                    for (int j = 0; j < EPL; ++j) acc_a[j] = 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < EPL; ++j) acc_a[j] += c0 * pv[j] + c1 * nv[j];
+                // positive row: LDS table of the workgroup's class, else straight to memory
+                if (c == cb && pr < RC) {
+#pragma unroll
+                    for (int j = 0; j < EPL; ++j) atomicAdd(cache + pr * E + s * EPL + j, c0 * av[j] + c2 * nv[j]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < EPL; ++j) atomicAdd(gxn + ip * E + s * EPL + j, c0 * av[j] + c2 * nv[j]);
+                }
+            }
+            // negative rows: whole contiguous rows per atomic wave-instruction via the wave-private slab
+            float* slab = stage + (threadIdx.x >> 6) * (8 * LD);
+            const int gi = lane >> 3;
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) slab[gi * LD + s * EPL + j] = live ? c1 * av[j] + c2 * pv[j] : 0.f;
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            constexpr int RPI = 64 / E;
+#pragma unroll
+            for (int r = 0; r < EPL; ++r) {
+                const int tl = r * RPI + lane / E, e = lane % E;
+                const int64_t rn = __shfl(in, tl * SUB, 64);
+                const bool lv = __shfl((int)live, tl * SUB, 64) != 0;
+                if (lv) atomicAdd(gxn + rn * E + e, slab[tl * LD + e]);
+            }
+        }
+    }
+    if (GRAD && cur >= 0) {
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) atomicAdd(gxn + cur * E + s * EPL + j, acc_a[j]);
+    }
+    const double lt = hpcs_block_sum<double>(acc_loss, red);
+    if (threadIdx.x == 0 && lt != 0.0) atomicAdd(loss_sum, lt);
+    const double kt = hpcs_block_sum<double>((double)kept, red);
+    if (threadIdx.x == 0 && kt != 0.0) atomicAdd(kept_out, (unsigned long long)kt);
+    if (GRAD) {
+        const double gt = hpcs_block_sum<double>(acc_gs, red);
+        if (threadIdx.x == 0 && gt != 0.0) atomicAdd(gscale, gt);
+        __syncthreads();
+        // flush the positive table: row r of the class -> point order[off_cb + r]; 64/E rows per wave instruction
+        const int rows = min(RC, cb_sh[2]);
+        const int off_cb = cb_sh[1];
+        constexpr int RPW = 64 / E;
+        const int wave = threadIdx.x >> 6;
+        for (int r0 = wave * RPW; r0 < rows; r0 += (SB_THREADS / 64) * RPW) {
+            const int r = r0 + lane / E, e = lane % E;
+            if (r < rows) {
+                const float v = cache[r * E + e];
+                if (v != 0.f) atomicAdd(gxn + (int64_t)order[off_cb + r] * E + e, v);
+            }
+        }
+    }
+}
+
 template <bool BWD>
 int launch_hyphc(const float* xn, int E, const int64_t* a, const int64_t* p, const int64_t* n, const int64_t* count,
                  int64_t T_cap, const float* scale, float temperature, float margin, int kind, const int64_t* norm_count,
@@ -828,6 +1030,53 @@ extern "C" int hpcs_triplet_margin_bwd(const float* xn, int E, const int64_t* a,
     if (T_cap == 0) return HPCS_OK;
     hipLaunchKernelGGL(triplet_margin_bwd_kernel, dim3(trip_grid(T_cap)), dim3(TPB), 0, ST, xn, E, a, p, n, count, T_cap,
                        margin, sum_and_nnz, gloss, gxn);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
+extern "C" int hpcs_hyphc_sampled(const float* xn, const int64_t* labels, const int32_t* order, const int32_t* offsets,
+                                  const int64_t* cls_toff, const int32_t* cls_k, int C, int M, int E, int64_t T,
+                                  uint64_t seed, const float* scale, float temperature, float margin, int kind,
+                                  double* loss_sum, int64_t* kept, float* gxn, double* gscale, int64_t* a_dbg,
+                                  int64_t* p_dbg, int64_t* n_dbg, hpcs_stream_t stream) {
+    if (!xn || !labels || !order || !offsets || !cls_toff || !cls_k || !scale || !loss_sum || !kept) return HPCS_ERR_NULL;
+    if ((gxn == nullptr) != (gscale == nullptr)) return HPCS_ERR_NULL;
+    if ((a_dbg || p_dbg || n_dbg) && !(a_dbg && p_dbg && n_dbg)) return HPCS_ERR_NULL;
+    if (C <= 0 || M <= 0 || T < 0 || !(temperature > 0.f) || kind > 3) return HPCS_ERR_SHAPE;
+    if (E != 16 && E != 32 && E != 64) return HPCS_ERR_UNSUPPORTED;
+    if (hipMemsetAsync(loss_sum, 0, sizeof(double), ST) != hipSuccess) return HPCS_ERR_HIP;
+    if (hipMemsetAsync(kept, 0, sizeof(int64_t), ST) != hipSuccess) return HPCS_ERR_HIP;
+    if (gscale && hipMemsetAsync(gscale, 0, sizeof(double), ST) != hipSuccess) return HPCS_ERR_HIP;
+    if (T == 0) return HPCS_OK;
+    const dim3 grid((unsigned)((T + SB_TB - 1) / SB_TB));
+    unsigned perm_mul = 1;
+    static const unsigned primes[] = {7919u, 7907u, 7901u, 7883u, 7879u, 7877u};
+    for (unsigned pm : primes)
+        if (grid.x % pm != 0) { perm_mul = pm; break; }
+    const bool grad = gxn != nullptr;
+    const int LD = E + 8;
+    const size_t slab_bytes = (size_t)(SB_THREADS / 64) * 8 * LD * sizeof(float);
+    int RC = grad ? (int)((128 * 1024 - slab_bytes) / (E * sizeof(float))) : 0;     // rows of the positive table
+    if (RC > 1024) RC = 1024;
+    const size_t lds = (size_t)RC * E * sizeof(float) + slab_bytes;
+#define HPCS_SAMPLED_CASE(EPL)                                                                                        \
+    if (E == 8 * EPL) {                                                                                               \
+        if (grad) {                                                                                                   \
+            (void)hipFuncSetAttribute((const void*)hyphc_sampled_kernel<EPL, true>,                                   \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                          \
+            hipLaunchKernelGGL((hyphc_sampled_kernel<EPL, true>), grid, dim3(SB_THREADS), lds, ST, xn, labels, order, \
+                               offsets, cls_toff, cls_k, C, M, T, seed, scale, temperature, margin, kind, RC, loss_sum, \
+                               (unsigned long long*)kept, gxn, gscale, a_dbg, p_dbg, n_dbg, perm_mul);                \
+        } else {                                                                                                      \
+            hipLaunchKernelGGL((hyphc_sampled_kernel<EPL, false>), grid, dim3(SB_THREADS), lds, ST, xn, labels, order, \
+                               offsets, cls_toff, cls_k, C, M, T, seed, scale, temperature, margin, kind, RC, loss_sum, \
+                               (unsigned long long*)kept, gxn, gscale, a_dbg, p_dbg, n_dbg, perm_mul);                \
+        }                                                                                                             \
+    }
+    HPCS_SAMPLED_CASE(2)
+    HPCS_SAMPLED_CASE(4)
+    HPCS_SAMPLED_CASE(8)
+#undef HPCS_SAMPLED_CASE
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;
 }

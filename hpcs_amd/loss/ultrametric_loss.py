@@ -100,6 +100,46 @@ class HypHCFn(torch.autograd.Function):
         return gxn, gscale, None, None, None, None, None, None, None
 
 
+class HypHCSampledFn(torch.autograd.Function):
+    """HypHC term with the class-balanced triplets generated INSIDE the kernel (device RNG): no index arrays, no
+    sampler / filter passes; loss, kept count and unscaled gradient in one sweep (hpcs_hyphc_sampled)."""
+
+    @staticmethod
+    def forward(ctx, xn, scale, labels, order, offsets, toff, kk, T, seed, temperature, margin, kind, debug):
+        M, E = xn.shape
+        dev = xn.device
+        C = kk.numel()
+        loss_sum = torch.empty(1, dtype=torch.float64, device=dev)
+        kept = torch.empty(1, dtype=torch.int64, device=dev)
+        need_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        gxn_raw = torch.zeros(M, E, device=dev) if need_grad else None
+        gscale_raw = torch.empty(1, dtype=torch.float64, device=dev) if need_grad else None
+        dbg = [None, None, None]
+        if debug is not None:
+            dbg = [torch.zeros(T, dtype=torch.int64, device=dev) for _ in range(3)]
+            debug.extend(dbg)
+        call("hpcs_hyphc_sampled", xn, labels, order, offsets, toff, kk, C, M, E, T, int(seed) & (2 ** 63 - 1), scale,
+             temperature, margin, _KIND[kind], loss_sum, kept, gxn_raw, gscale_raw, dbg[0], dbg[1], dbg[2])
+        _LAST_KEPT[0] = kept
+        colsum = torch.empty(E, dtype=torch.float64, device=dev)
+        call("hpcs_colsum", xn, M, E, colsum)
+        mean_sim = 0.5 + 0.5 * (colsum * colsum).sum() / float(M * M)
+        out = loss_sum[0] / kept[0].double() + mean_sim
+        ctx.save_for_backward(scale, colsum, kept, gxn_raw, gscale_raw)
+        ctx.M = M
+        return out.float()
+
+    @staticmethod
+    def backward(ctx, g):
+        scale, colsum, kept, gxn_raw, gscale_raw = ctx.saved_tensors
+        M = ctx.M
+        g32 = g.reshape(1).float()
+        inv = (g32.double() / kept.double().clamp_min(1)).float()
+        gxn = torch.addcmul((colsum / float(M * M)).float().mul(g32).unsqueeze(0), gxn_raw, inv)
+        gscale = (gscale_raw * inv.double()).float().view_as(scale)
+        return (gxn, gscale) + (None,) * 11
+
+
 class CosFaceFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xn, wn, labels, margin, scale, branch_id):
@@ -204,6 +244,8 @@ class MetricHyperbolicLoss(torch.nn.Module):
                                                           type_of_triplets="semihard", rng=rng)
             self.loss_triplet = TripletMarginLoss(distance=self.distance_sim, margin=margin)
         self.last_triplets = None
+        self.last_T = 0
+        self.debug_triplets = None      # tests: set to a list to receive the triplets generated in-kernel
 
     # ---- pieces ------------------------------------------------------------------------------------------
     def _scale_tensor(self, like):
@@ -227,11 +269,25 @@ class MetricHyperbolicLoss(torch.nn.Module):
         if triplets is None:
             if self.miner and self.fused_filter:
                 # sample only; the 'easy'/margin-0 rule of hyp_miner is evaluated inside the loss kernels
-                from ..miner.loss_and_miner_utils import TripletPlan, sample_with_plan
+                from ..miner.loss_and_miner_utils import TripletPlan, class_index, sample_with_plan
+                from .._pinned import upload
                 m = self.hyp_miner
                 if plan is None:
                     plan = TripletPlan.from_labels(labels, m.t_per_anchor, m.fraction)
                 m.seed += 1
+                if m.rng == "device" and xn.shape[1] in (16, 32, 64) and plan.T > 0:
+                    # device RNG: triplets are generated inside the loss kernel (no index arrays at all)
+                    lab = labels.reshape(-1).to(torch.int64).contiguous()
+                    order, offsets = class_index(lab, plan.C)
+                    toff = upload(plan.toff, xn.device, key="plan")
+                    kk = upload(plan.k, xn.device, key="plan")
+                    self.last_triplets = None
+                    self.last_T = plan.T
+                    out = HypHCSampledFn.apply(xn, self._scale_tensor(xn), lab, order, offsets, toff, kk, plan.T, m.seed,
+                                               float(self.temperature), float(m.margin), m.type_of_triplets,
+                                               self.debug_triplets)
+                    self.last_kept = _LAST_KEPT[0]
+                    return out
                 a, p, n = sample_with_plan(labels, plan, rng=m.rng, seed=m.seed)
                 triplets = (a, p, n, torch.full((1,), a.numel(), dtype=torch.int64, device=xn.device))
                 kind, margin = m.type_of_triplets, float(m.margin)
@@ -241,6 +297,7 @@ class MetricHyperbolicLoss(torch.nn.Module):
                 triplets = self.get_triplets(x_poincare.shape[0], x_poincare.device)
         a, p, n, count = triplets
         self.last_triplets = triplets
+        self.last_T = a.numel()
         scale = self._scale_tensor(xn)
         out = HypHCFn.apply(xn, scale, a, p, n, count, float(self.temperature), margin, kind)
         self.last_kept = _LAST_KEPT[0]

@@ -58,6 +58,18 @@ class TripletPlan:
         return torch.cat(pos), torch.cat(neg)
 
 
+def class_index(labels, C):
+    """labels int64 [M] on the device -> (order int32 [M]: members grouped by class in ascending index,
+    offsets int32 [C+1])."""
+    dev = labels.device
+    M = labels.numel()
+    order = torch.empty(M, dtype=torch.int32, device=dev)
+    offsets = torch.empty(C + 1, dtype=torch.int32, device=dev)
+    counts_ws = torch.empty(C, dtype=torch.int32, device=dev)
+    _lib.call("hpcs_class_index", labels, M, C, order, offsets, counts_ws)
+    return order, offsets
+
+
 def sample_with_plan(labels, plan, rng="host", seed=0):
     """labels: int64 [M] on the device.  Returns (a, p, n) int64 [T] on the device."""
     dev = labels.device
@@ -70,10 +82,7 @@ def sample_with_plan(labels, plan, rng="host", seed=0):
     n = torch.empty(T, dtype=torch.int64, device=dev)
     if T == 0:
         return a, p, n
-    order = torch.empty(M, dtype=torch.int32, device=dev)
-    offsets = torch.empty(C + 1, dtype=torch.int32, device=dev)
-    counts_ws = torch.empty(C, dtype=torch.int32, device=dev)
-    _lib.call("hpcs_class_index", labels, M, C, order, offsets, counts_ws)
+    order, offsets = class_index(labels, C)
     from .._pinned import upload
     toff = upload(plan.toff, dev, key="plan")
     kk = upload(plan.k, dev, key="plan")

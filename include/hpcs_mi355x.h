@@ -230,6 +230,16 @@ int hpcs_hyphc_bwd(const float* xn, int E, const int64_t* a, const int64_t* p, c
                    const int64_t* count, int64_t T_cap, const float* scale, float temperature, float margin,
                    int kind, const int64_t* norm_count, const float* gloss, float* gxn, double* gscale,
                    double* loss_sum, int64_t* kept, hpcs_stream_t stream);
+/* hyphc_sampled: the training-path form for the device RNG.  Triplets are generated INSIDE the kernel from
+ * (class index, per-class plan, seed) -- no index arrays, no sampler/filter pass -- the margin rule `kind` is applied
+ * inline, and loss_sum[1], kept[1] and (gxn != NULL) the UNSCALED gradient gxn [M,E] (accumulated into; caller
+ * zero-fills) + gscale[1] come out of one sweep.  Positive-row gradients are accumulated in an LDS table per
+ * workgroup.  E must be 16, 32 or 64.  a_dbg/p_dbg/n_dbg (nullable, [T]) receive the generated triplets (tests). */
+int hpcs_hyphc_sampled(const float* xn, const int64_t* labels, const int32_t* order, const int32_t* offsets,
+                       const int64_t* cls_toff, const int32_t* cls_k, int C, int M, int E, int64_t T, uint64_t seed,
+                       const float* scale, float temperature, float margin, int kind, double* loss_sum, int64_t* kept,
+                       float* gxn, double* gscale, int64_t* a_dbg, int64_t* p_dbg, int64_t* n_dbg,
+                       hpcs_stream_t stream);
 /* mean of the M x M similarity in closed form: 0.5 + 0.5*|sum_i xn_i|^2/M^2.  colsum [E] double. */
 int hpcs_colsum(const float* xn, int64_t rows, int E, double* colsum, hpcs_stream_t stream);
 /* cosface: plain CosFace = one level of singleton branches (branch_id NULL, n_levels 1).  Hierarchical CosFace

@@ -233,3 +233,44 @@ def test_hierarchical_cosface_loss_and_grads():
     flat.W.data.copy_(W)
     plain.W.data.copy_(W)
     assert abs(float(flat(x.to(dev), lab.to(dev))) - float(plain(x.to(dev), lab.to(dev)))) < 1e-6
+
+
+def test_hyphc_sampled_in_kernel():
+    """The training-path kernel (triplets generated in-kernel, LDS positive table) against the array-based kernels
+    run on the very triplets it generated, plus validity / balance of those triplets."""
+    from hpcs_amd.loss.ultrametric_loss import MetricHyperbolicLoss, HypHCFn, L2RowsFn
+    M, E, C = 6000, 32, 7
+    x = OH.expmap0(det_normalish((M, E), 61) * 0.5)
+    lab = torch.cat([det_int((M - 900,), 62, C - 1), torch.full((900,), C - 1)])        # one large class
+    crit = MetricHyperbolicLoss(t_per_anchor=9, fraction=1.2, scale=torch.nn.Parameter(torch.tensor([0.03])),
+                                temperature=0.05, num_class=C, embedding_size=E, cosface=True, miner=True, rng="device",
+                                fused_filter=True).to(dev)
+    crit.debug_triplets = []
+    xg = x.to(dev).requires_grad_(True)
+    lh = crit.compute_hyp(xg, lab.to(dev))
+    lh.backward()
+    a, p, n = crit.debug_triplets
+    T = a.numel()
+    plan = crit.make_plan(lab)
+    assert T == plan.T == crit.last_T
+    la, lp, ln = lab[a.cpu()], lab[p.cpu()], lab[n.cpu()]
+    assert bool((la == lp).all()) and bool((a != p).all()) and bool((la != ln).all())
+    cnt = torch.bincount(a.cpu(), minlength=M)
+    assert bool((cnt == plan.k[lab].long()).all())                 # every anchor exactly k_l times
+    neg_hist = torch.bincount(n.cpu(), minlength=M).float()      # ~Poisson: relative spread ~ 1/sqrt(mean)
+    assert float(neg_hist.std() / neg_hist.mean()) < 1.5 / float(neg_hist.mean()) ** 0.5
+    # same triplets through the array-based one-pass kernel
+    x2 = x.to(dev).requires_grad_(True)
+    sc2 = torch.tensor([0.03], device=dev, requires_grad=True)
+    cnt_t = torch.full((1,), T, dtype=torch.int64, device=dev)
+    l2 = HypHCFn.apply(L2RowsFn.apply(x2), sc2, a, p, n, cnt_t, 0.05, 0.0, "easy")
+    l2.backward()
+    assert abs(float(lh) - float(l2)) <= 2e-6 * abs(float(l2))
+    relclose(xg.grad, x2.grad, 2e-5)
+    assert abs(float(crit.scale.grad) - float(sc2.grad)) <= 1e-4 * abs(float(sc2.grad))
+    # no-grad call takes the gradient-free instantiation and agrees
+    crit.debug_triplets = None
+    crit.hyp_miner.seed -= 1
+    with torch.no_grad():
+        l3 = crit.compute_hyp(x.to(dev), lab.to(dev))
+    assert abs(float(l3) - float(lh)) <= 2e-6 * abs(float(lh))
