@@ -1,3 +1,7 @@
-__all__ = ["ExpMap", "MLPExpMap"]
+"""Poincare-ball embedding heads (mirror of the `hpcs.nn.hyperbolic` namespace)."""
+from . import hyp_embed as _hyp_embed
 
-from .hyp_embed import ExpMap, MLPExpMap
+ExpMap = _hyp_embed.ExpMap
+MLPExpMap = _hyp_embed.MLPExpMap
+
+__all__ = ("ExpMap", "MLPExpMap")
