@@ -199,6 +199,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         losses = step.training_step(pts_d, cat_d, tgt_d, targets_host=tgt)
+    dt_host = time.perf_counter() - t0          # launches enqueued; the GPU may still be running
     barrier()
     dt = time.perf_counter() - t0
     prof, _lib.PROFILE = _lib.PROFILE, None
@@ -236,6 +237,7 @@ def main():
                    "parallelism": f"dp{world} (per-replica BN and mining, one flat-gradient all-reduce)",
                    "triplet_rng": "device counter RNG (statistically equivalent to the reference's CPU torch.randint)",
                    "metrics_in_step": "accuracy/IoU logging off", "final_total_loss": round(loss_val, 6),
+                   "host_enqueue_ms_per_step": round(dt_host / args.steps * 1e3, 3),
                    "triplets_sampled_per_step_rank0": int(step.metric_hyp_loss.last_T)},
     }
     if timed and prof:

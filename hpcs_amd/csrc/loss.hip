@@ -498,8 +498,8 @@ __global__ __launch_bounds__(TPB) void hyphc_kernel(const float* __restrict__ xn
 // rows are random over the cloud and use the row-contiguous global atomic shape.
 constexpr int SB_THREADS = 1024;
 constexpr int SB_GROUPS = SB_THREADS / SUB;      // 128
-constexpr int SB_SEG = 128;                      // triplets per 8-lane group
-constexpr int SB_TB = SB_GROUPS * SB_SEG;        // 16384 triplets per workgroup
+constexpr int SB_SEG_MAX = 128;                  // triplets per 8-lane group: chosen per launch (multiple of 8) so that the
+constexpr int SB_SEG_MIN = 16;                   // workgroup count fills whole rounds of one-workgroup-per-CU residency
 
 __device__ __forceinline__ int class_of(const int64_t* __restrict__ toff, int C, int64_t t) {
     int lo = 0, hi = C;
@@ -518,7 +518,7 @@ __global__ __launch_bounds__(SB_THREADS) void hyphc_sampled_kernel(
     int M, int64_t T, uint64_t seed, const float* __restrict__ scale, float temperature, float margin, int kind, int RC,
     double* __restrict__ loss_sum, unsigned long long* __restrict__ kept_out, float* __restrict__ gxn,
     double* __restrict__ gscale, int64_t* __restrict__ a_dbg, int64_t* __restrict__ p_dbg, int64_t* __restrict__ n_dbg,
-    unsigned perm_mul) {
+    unsigned perm_mul, int seg_len) {
     constexpr int E = 8 * EPL;
     using IO = RowIO<EPL, true>;
     constexpr int LD = E + 8;
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(SB_THREADS) void hyphc_sampled_kernel(
     const int s = threadIdx.x % SUB, g = threadIdx.x / SUB;
     const int sub0 = lane & ~(SUB - 1);
     const unsigned pblock = (unsigned)(((uint64_t)blockIdx.x * perm_mul) % gridDim.x);
-    const int64_t block_base = (int64_t)pblock * SB_TB;
+    const int64_t block_base = (int64_t)pblock * ((int64_t)SB_GROUPS * seg_len);
 
     if (threadIdx.x == 0) {
         const int cb = class_of(cls_toff, C, block_base < T ? block_base : T - 1);
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(SB_THREADS) void hyphc_sampled_kernel(
     __syncthreads();
     const int cb = cb_sh[0];
 
-    const int64_t seg = block_base + (int64_t)g * SB_SEG;
+    const int64_t seg = block_base + (int64_t)g * seg_len;
     // lane-private class cursor (all 8 lanes of a group are within a few triplets of each other)
     int c = class_of(cls_toff, C, seg < T ? seg : T - 1);
     int64_t c_t0 = cls_toff[c], c_t1 = cls_toff[c + 1];
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(SB_THREADS) void hyphc_sampled_kernel(
 #pragma unroll
     for (int j = 0; j < EPL; ++j) acc_a[j] = 0.f;
 
-    for (int b8 = 0; b8 < SB_SEG / SUB; ++b8) {
+    for (int b8 = 0; b8 < seg_len / SUB; ++b8) {
         // ---- lane s generates triplet (seg + 8*b8 + s): eight index chains in flight per group --------------------
         const int64_t tl = seg + b8 * SUB + s;
         const bool lv_own = tl < T;
@@ -1112,7 +1112,32 @@ extern "C" int hpcs_hyphc_sampled(const float* xn, const int64_t* labels, const 
     if (hipMemsetAsync(kept, 0, sizeof(int64_t), ST) != hipSuccess) return HPCS_ERR_HIP;
     if (gscale && hipMemsetAsync(gscale, 0, sizeof(double), ST) != hipSuccess) return HPCS_ERR_HIP;
     if (T == 0) return HPCS_OK;
-    const dim3 grid((unsigned)((T + SB_TB - 1) / SB_TB));
+    // Workgroups are resident one per CU (128 KB of LDS), so the grid runs in rounds of n_cu workgroups: pick the
+    // segment length (multiple of 8) that wastes the least of the last round; ties go to the longer segment, which
+    // amortises the positive table's zero/flush best.  The triplet stream depends on (seed, t) only, not on this.
+    static int n_cu = 0;
+    static int seg_env = -1;
+    if (n_cu == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+            v = 256;
+        n_cu = v;
+        const char* e = getenv("HPCS_SAMPLED_SEG");          // tuning override (multiple of 8 in [8, 128])
+        seg_env = e ? atoi(e) : 0;
+    }
+    int seg_len = SB_SEG_MAX;
+    if (seg_env >= 8 && seg_env <= SB_SEG_MAX && seg_env % 8 == 0) {
+        seg_len = seg_env;
+    } else {
+        int64_t best = INT64_MAX;
+        for (int sl = SB_SEG_MAX; sl >= SB_SEG_MIN; sl -= 8) {
+            const int64_t blocks = (T + (int64_t)SB_GROUPS * sl - 1) / ((int64_t)SB_GROUPS * sl);
+            const int64_t cost = ((blocks + n_cu - 1) / n_cu) * sl;
+            if (cost < best) { best = cost; seg_len = sl; }
+        }
+    }
+    const int64_t tb = (int64_t)SB_GROUPS * seg_len;
+    const dim3 grid((unsigned)((T + tb - 1) / tb));
     unsigned perm_mul = 1;
     static const unsigned primes[] = {7919u, 7907u, 7901u, 7883u, 7879u, 7877u};
     for (unsigned pm : primes)
@@ -1131,11 +1156,11 @@ extern "C" int hpcs_hyphc_sampled(const float* xn, const int64_t* labels, const 
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                          \
             hipLaunchKernelGGL((hyphc_sampled_kernel<EPL, true>), grid, dim3(SB_THREADS), lds, ST, xn, labels, order, \
                                offsets, cls_toff, cls_k, C, M, T, seed, scale, temperature, margin, kind, RC, loss_sum, \
-                               (unsigned long long*)kept, gxn, gscale, a_dbg, p_dbg, n_dbg, perm_mul);                \
+                               (unsigned long long*)kept, gxn, gscale, a_dbg, p_dbg, n_dbg, perm_mul, seg_len);                \
         } else {                                                                                                      \
             hipLaunchKernelGGL((hyphc_sampled_kernel<EPL, false>), grid, dim3(SB_THREADS), lds, ST, xn, labels, order, \
                                offsets, cls_toff, cls_k, C, M, T, seed, scale, temperature, margin, kind, RC, loss_sum, \
-                               (unsigned long long*)kept, gxn, gscale, a_dbg, p_dbg, n_dbg, perm_mul);                \
+                               (unsigned long long*)kept, gxn, gscale, a_dbg, p_dbg, n_dbg, perm_mul, seg_len);                \
         }                                                                                                             \
     }
     HPCS_SAMPLED_CASE(2)

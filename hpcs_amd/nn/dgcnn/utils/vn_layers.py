@@ -24,7 +24,7 @@ class VNLinear(nn.Module):                                     # vn_layers.py:13
         self.map_to_feat = nn.Linear(in_channels, out_channels, bias=False)
 
     def forward(self, x):
-        return ops.chan_mix(_flat(x), self.map_to_feat.weight)
+        return ops.chan_mix(_flat(x), self.map_to_feat.weight, sink=(self.map_to_feat.weight, ...))
 
 
 class VNLeakyReLU(nn.Module):                                  # vn_layers.py:27-45
@@ -126,7 +126,7 @@ class VNStdFeature(nn.Module):                                 # vn_layers.py:15
 
     def frame(self, x, xconst=None):
         z = self.vn2(self.vn1(x, xconst=xconst))
-        z = ops.chan_mix(z, self.vn_lin.weight)        # [B,3,3,N]
+        z = ops.chan_mix(z, self.vn_lin.weight, sink=(self.vn_lin.weight, ...))        # [B,3,3,N]
         return z.transpose(1, 2).contiguous()
 
     def forward(self, x):

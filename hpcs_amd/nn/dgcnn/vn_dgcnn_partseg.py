@@ -89,7 +89,7 @@ class VN_DGCNN_partseg(nn.Module):
 
     def _head(self, seq, x, rowbias=None, mask=None):
         conv, bn = seq[0], seq[1]
-        y = ops.chan_mix(x, conv.weight[:, :, 0], rowbias)
+        y = ops.chan_mix(x, conv.weight[:, :, 0], rowbias, sink=(conv.weight, (slice(None), slice(None), 0)))
         slope = 0.2 if len(seq) > 2 else 1.0
         out = ops.bn_act(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training, slope, mask)
         if self.training:
@@ -129,8 +129,10 @@ class VN_DGCNN_partseg(nn.Module):
         vec = torch.cat((glob, cat.view(B, -1)), dim=1)                         # [B,2110]
 
         W8 = self.conv8[0].weight[:, :, 0]
-        bias8 = ops.chan_mix(vec.unsqueeze(-1), W8[:, :self._glob_ch]).view(B, -1)          # [B,256]
-        y8 = ops.chan_mix(loc, W8[:, self._glob_ch:], bias8)
+        W8p, gc = self.conv8[0].weight, self._glob_ch
+        bias8 = ops.chan_mix(vec.unsqueeze(-1), W8[:, :gc],
+                             sink=(W8p, (slice(None), slice(0, gc), 0))).view(B, -1)        # [B,256]
+        y8 = ops.chan_mix(loc, W8[:, gc:], bias8, sink=(W8p, (slice(None), slice(gc, None), 0)))
         bn = self.bn8
         m1 = self._drop_mask(y8, self.dropout, None if drop_masks is None else drop_masks[0])
         hh = ops.bn_act(y8, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training, 0.2, m1)

@@ -20,7 +20,8 @@ class MLPExpMap(nn.Module):
         from ... import ops
         lin, drop = self.mlp[0][0], self.mlp[0][1]
         B = x.shape[0]
-        y = ops.chan_mix(x.reshape(1, -1, x.shape[-1]).transpose(1, 2).contiguous(), lin.weight)   # [1,out,rows]
+        y = ops.chan_mix(x.reshape(1, -1, x.shape[-1]).transpose(1, 2).contiguous(), lin.weight,
+                         sink=(lin.weight, ...))   # [1,out,rows]
         y = y.transpose(1, 2).reshape(*x.shape[:-1], -1)
         if lin.bias is not None:
             y = y + lin.bias

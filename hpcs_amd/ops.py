@@ -82,6 +82,60 @@ def gemm_GXt(G, X, nb, M, K, Nc):
     return dW
 
 
+# ------------------------------------------------------------------------------------------------ side-stream dW
+class _SideWGrad:
+    """Weight-gradient GEMMs are off the backward critical path (nothing consumes dW before the optimiser), so inside
+    `deferred_weight_grads()` they run on a second HIP stream and add straight into the parameter's `.grad` (the flat
+    bucket of dp.py) while the main stream continues with the data-gradient chain: the MFMA-bound dW kernels overlap
+    the HBM-bound element-wise passes.  Outside the context (or for parameters without a pre-allocated `.grad`)
+    dW is returned to autograd as usual."""
+    enabled = False
+    stream = None
+    used = False
+    keep = []
+
+
+class deferred_weight_grads:
+    """Context manager around `loss.backward()`; on exit the main stream waits for the side stream."""
+
+    def __enter__(self):
+        if _SideWGrad.stream is None:
+            _SideWGrad.stream = torch.cuda.Stream()
+        _SideWGrad.enabled = True
+        return self
+
+    def __exit__(self, *exc):
+        _SideWGrad.enabled = False
+        if _SideWGrad.used:
+            torch.cuda.current_stream().wait_stream(_SideWGrad.stream)
+            _SideWGrad.used = False
+        _SideWGrad.keep.clear()
+        return False
+
+
+def _grad_sink(spec):
+    """spec = (parameter, index) -> the view of parameter.grad that dW accumulates into, or None."""
+    if not _SideWGrad.enabled or spec is None:
+        return None
+    p, index = spec
+    if not (p.is_leaf and p.requires_grad and p.grad is not None and p.grad.is_cuda):
+        return None
+    return p.grad[index]
+
+
+def _on_side_stream(work, keep_alive):
+    main = torch.cuda.current_stream()
+    side = _SideWGrad.stream
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        work()
+    # operands were allocated on the main stream and are read on the side stream: keep them referenced until the main
+    # stream has waited for the side stream (__exit__), so the caching allocator cannot hand their blocks out earlier
+    # (cheaper than Tensor.record_stream, whose deferred frees made the allocator fall back to hipMalloc/hipFree)
+    _SideWGrad.keep.append(keep_alive)
+    _SideWGrad.used = True
+
+
 # ------------------------------------------------------------------------------------------------ a1 / a2
 def knn(x, k):
     _need_cuda(x)
@@ -127,7 +181,8 @@ class ChanMixFn(torch.autograd.Function):
     """y[b,o,...] = sum_c W[o,c] x[b,c,...] (+ rowbias[b,o])  (nn.Linear over dim 1; Conv1d k=1)."""
 
     @staticmethod
-    def forward(ctx, x, W, rowbias=None):
+    def forward(ctx, x, W, rowbias=None, sink=None):
+        ctx.sink = sink
         x = _f32c(x)
         W = _f32c(W)
         B, K = x.shape[0], x.shape[1]
@@ -154,16 +209,22 @@ class ChanMixFn(torch.autograd.Function):
             call("hpcs_gemm_tn", Wp, Wp.shape[1], g, Nc, M * Nc, 0, gx, Nc, K * Nc, 0, K, Nc, M, B, 1, None, 0)
             gx = gx.view_as(x)
         if ctx.needs_input_grad[1]:
-            gW = gemm_GXt(g, x, B, M, K, Nc)
+            dst = _grad_sink(ctx.sink)
+            if dst is not None:
+                _on_side_stream(lambda: dst.add_(gemm_GXt(g, x, B, M, K, Nc)), (g, x))
+            else:
+                gW = gemm_GXt(g, x, B, M, K, Nc)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = torch.empty(B, M, device=g.device)
             call("hpcs_rowsum", g, B * M, Nc, 1.0, gb)
-        return gx, gW, gb
+        return gx, gW, gb, None
 
 
-def chan_mix(x, W, rowbias=None):
+def chan_mix(x, W, rowbias=None, sink=None):
+    """sink = (parameter, index) with parameter[index] == W: lets the backward add dW into parameter.grad[index] on the
+    side stream (see deferred_weight_grads)."""
     _need_cuda(x, W)
-    return ChanMixFn.apply(x, W, rowbias)
+    return ChanMixFn.apply(x, W, rowbias, sink)
 
 
 # ------------------------------------------------------------------------------------------------ a3
@@ -187,6 +248,7 @@ class VNLayerFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, Wf, Wd, gamma, beta, rmean, rvar, training, slope, pool_k, flags, xconst):
+        ctx.wparams = (Wf, Wd)
         x = _f32c(x)
         B, Cin = x.shape[0], x.shape[1]
         L = x[0, 0, 0].numel()
@@ -256,11 +318,28 @@ class VNLayerFn(torch.autograd.Function):
                 call("hpcs_gemm_tn", Wc, Wc.shape[1], S, 3, Ctot * 3, 0, gxc, 3, Cc * 3, 0, Cc, 3, Ctot, B, 1, None, 0)
                 gxc = gxc.view(B, Cc, 3)
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            gWcat = gemm_GXt(GPD, x, B, Ctot, Cin, 3 * L)
-            if Cc:
-                gWcat = torch.cat([gWcat, gemm_GXt(S, xconst, B, Ctot, Cc, 3)], dim=1)
-            gW = gWcat[:Cout]
-            gWd = gWcat[Cout:] if Cd else None
+            def weight_grads():
+                gWcat = gemm_GXt(GPD, x, B, Ctot, Cin, 3 * L)
+                if Cc:
+                    gWcat = torch.cat([gWcat, gemm_GXt(S, xconst, B, Ctot, Cc, 3)], dim=1)
+                return gWcat
+
+            Wf_, Wd_ = ctx.wparams
+            sink_f = _grad_sink((Wf_, ...)) if ctx.needs_input_grad[1] else None
+            sink_d = _grad_sink((Wd_, ...)) if (Cd and ctx.needs_input_grad[2]) else None
+            if (sink_f is not None or not ctx.needs_input_grad[1]) and \
+                    (sink_d is not None or not (Cd and ctx.needs_input_grad[2])):
+                def work():
+                    gWcat = weight_grads()
+                    if sink_f is not None:
+                        sink_f.add_(gWcat[:Cout])
+                    if sink_d is not None:
+                        sink_d.add_(gWcat[Cout:])
+                _on_side_stream(work, (GPD, x, S, xconst))
+            else:
+                gWcat = weight_grads()
+                gW = gWcat[:Cout]
+                gWd = gWcat[Cout:] if Cd else None
         if flags & VN_BN:
             gbeta = red[:Cout].float()
             ggamma = red[Cout:].float()

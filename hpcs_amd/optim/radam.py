@@ -12,13 +12,14 @@ from .. import _lib
 
 
 class RAdam(torch.optim.Adam):
-    def _table(self, group, params):
-        """Device table: descriptors + row starts (rebuilt when the tensors or step sizes change)."""
+    def _tables(self, group, params):
+        """Device tables (descriptors + row starts), rebuilt every step because the step sizes change.  Tensors whose
+        points are one-dimensional (Conv1d weights [Co,Ci,1], `scale`) go to a table walked with one lane per row,
+        the others with eight lanes per row; the step sizes follow the reference's parameter order either way."""
         import struct
         b1, b2 = group["betas"]
         lr = group["lr"]
-        blob = bytearray()
-        row_starts, rows_total = [], 0
+        entries = {1: [], 8: []}
         for p in params:
             st = self.state[p]
             group["step"] += 1
@@ -27,14 +28,22 @@ class RAdam(torch.optim.Adam):
             group["step"] += 1
             cols = p.shape[-1] if p.dim() > 0 else 1
             rows = p.numel() // cols
-            blob += struct.pack("<QQQQqif", p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(),
-                                st["exp_avg_sq"].data_ptr(), rows, cols, step_size)
+            entries[1 if cols == 1 else 8].append(
+                (p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), rows, cols, step_size))
+        out = []
+        for lanes, ents in entries.items():
+            if not ents:
+                continue
+            blob = bytearray()
+            row_starts, rows_total = [], 0
+            for e in ents:
+                blob += struct.pack("<QQQQqif", *e)
+                row_starts.append(rows_total)
+                rows_total += e[4]
             row_starts.append(rows_total)
-            rows_total += rows
-        row_starts.append(rows_total)
-        blob += struct.pack(f"<{len(row_starts)}q", *row_starts)
-        host = torch.frombuffer(blob, dtype=torch.uint8)
-        return host, rows_total
+            blob += struct.pack(f"<{len(row_starts)}q", *row_starts)
+            out.append((lanes, torch.frombuffer(blob, dtype=torch.uint8), len(ents), rows_total))
+        return out
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -65,10 +74,13 @@ class RAdam(torch.optim.Adam):
                 params.append(p)
             if not params:
                 continue
-            host, rows_total = self._table(group, params)
             from .._pinned import upload
-            dev_table = upload(host, params[0].device, key="radam")       # async, through a pinned ring
             b1, b2 = group["betas"]
-            _lib.call("hpcs_radam_step", dev_table, len(params), rows_total, b1, b2, group["eps"], group["weight_decay"])
-            self._keep = dev_table     # keep the table alive until the kernel has consumed it
+            keep = []
+            for lanes, host, n_tensors, rows_total in self._tables(group, params):
+                dev_table = upload(host, params[0].device, key=f"radam{lanes}")       # async, through a pinned ring
+                _lib.call("hpcs_radam_step", dev_table, n_tensors, rows_total, lanes, b1, b2, group["eps"],
+                          group["weight_decay"])
+                keep.append(dev_table)
+            self._keep = keep          # keep the tables alive until the kernels have consumed them
         return loss

@@ -11,6 +11,7 @@ import torch
 
 from .dp import FlatGradBucket
 from .loss.ultrametric_loss import HierarchicalMetricHyperbolicLoss, MetricHyperbolicLoss
+from .ops import deferred_weight_grads
 from .optim import RAdam
 
 
@@ -50,6 +51,7 @@ class HypHCStep(torch.nn.Module):
         else:
             self.metric_hyp_loss = MetricHyperbolicLoss(cosface=cosface, **common)
         self.lr = lr
+        self.side_stream_wgrad = True
         self.optimizer = None
         self.bucket = None
 
@@ -86,7 +88,11 @@ class HypHCStep(torch.nn.Module):
         self.bucket.zero()
         losses = self.forward_losses(points, label, targets, plan=plan, rot=rot, drop_masks=drop_masks)
         total = losses["loss_metric"] + losses["loss_hyp"]
-        total.backward()
+        if self.side_stream_wgrad:             # dW GEMMs on a side stream, joined before the all-reduce
+            with deferred_weight_grads():
+                total.backward()
+        else:
+            total.backward()
         self.bucket.all_reduce_mean()
         self.optimizer.step()
         losses["total_loss"] = total.detach()

@@ -265,15 +265,16 @@ int hpcs_triplet_margin_bwd(const float* xn, int E, const int64_t* a, const int6
  * (device pointers as uint64, rows*cols elements, `cols` = size of the last dim = the "point").
  * step_sizes[i] = lr*sqrt(1-b2^t)/(1-b1^t) with the reference's per-parameter double increment of
  * group["step"] (host-computed).  Applies egrad2rgrad, moment updates, expmap retraction, project
- * (row-norm clip 1-4e-3) and parallel transport of exp_avg. */
+ * (row-norm clip 1-4e-3) and parallel transport of exp_avg.  lanes_per_row = 8 (vector points) or 1 (tables
+ * whose tensors all have cols == 1: same arithmetic, one lane per row). */
 typedef struct {
     uint64_t param, grad, exp_avg, exp_avg_sq;
     int64_t rows;
     int32_t cols;
     float step_size;
 } hpcs_radam_desc;
-int hpcs_radam_step(const hpcs_radam_desc* desc_dev, int n_tensors, int64_t total_rows_hint, float beta1,
-                    float beta2, float eps, float weight_decay, hpcs_stream_t stream);
+int hpcs_radam_step(const hpcs_radam_desc* desc_dev, int n_tensors, int64_t total_rows_hint, int lanes_per_row,
+                    float beta1, float beta2, float eps, float weight_decay, hpcs_stream_t stream);
 
 /* flat fp32 helpers used by the data-parallel wrapper (gradient bucket pack/unpack+scale) */
 int hpcs_scale_inplace(float* x, int64_t n, float s, hpcs_stream_t stream);

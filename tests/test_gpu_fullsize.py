@@ -105,3 +105,33 @@ def test_loss_full_size_properties():
     # triplet bookkeeping: kept <= sampled, both as planned on the host
     plan = crit.make_plan(lab.cpu())
     assert crit.last_T == plan.T and 0 < int(crit.last_kept) <= plan.T
+
+
+def test_side_stream_weight_grads_match_inline():
+    """The dW GEMMs run on a second stream and add into the flat bucket (ops.deferred_weight_grads); the gradients
+    must equal the in-line autograd path (same kernels, 0 + dW accumulation) up to the run-to-run atomics noise."""
+    from hpcs_amd.nn.dgcnn import VN_DGCNN_partseg
+    from hpcs_amd.nn.hyperbolic import ExpMap
+    from hpcs_amd.step import HypHCStep, random_rotations
+    B, N, E, C = 4, 512, 32, 50
+    x = det_cloud(B, N, 511).to(dev).transpose(1, 2).contiguous()
+    cat = det_int((B,), 512, 16).to(dev)
+    tgt = det_int((B, N), 513, C)
+    R = random_rotations(B, dev)
+    masks = tuple(torch.empty(B, 256, N, device=dev).bernoulli_(0.5).mul_(2.0) for _ in range(2))
+    flats = []
+    for side in (False, True, True):
+        torch.manual_seed(5)                        # the CosFace class weights are drawn at construction
+        net = VN_DGCNN_partseg(3, E, k=20, dropout=0.5, pooling="mean", num_categories=16)
+        net.load_state_dict(det_params(OE.param_shapes(E, 16), 78))
+        step = HypHCStep(net, ExpMap(), hyp_size=E, num_class=C, lr=0.0, margin=0.35, t_per_anchor=50, fraction=1.2,
+                         rng="device").to(dev).configure()
+        step.side_stream_wgrad = side
+        step.training_step(x, cat, tgt.to(dev), targets_host=tgt, rot=R, drop_masks=masks)
+        torch.cuda.synchronize()
+        flats.append(step.bucket.flat.clone())
+    assert torch.isfinite(flats[0]).all() and float(flats[0].abs().sum()) > 0
+    # the loss kernel's fp32 atomics make runs differ in the last bits; a missed or raced dW would be O(1)
+    noise = float((flats[1] - flats[2]).norm() / flats[1].norm())
+    assert noise < 1e-4
+    assert float((flats[0] - flats[1]).norm() / flats[0].norm()) < max(1e-5, 4 * noise)
