@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from ... import ops
-from .utils.vn_layers import VNLinearLeakyReLU, VNMaxPool, VNStdFeature, mean_pool
+from .utils.vn_layers import VNLinearLeakyReLU, VNMaxPool, VNStdFeature, batch_counters, bump, mean_pool
 from .utils.vn_dgcnn_util import get_graph_feature, knn
 
 
@@ -93,7 +93,7 @@ class VN_DGCNN_partseg(nn.Module):
         slope = 0.2 if len(seq) > 2 else 1.0
         out = ops.bn_act(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training, slope, mask)
         if self.training:
-            bn.num_batches_tracked.add_(1)
+            bump(bn)
         return out
 
     def _drop_mask(self, like, p, given):
@@ -108,6 +108,10 @@ class VN_DGCNN_partseg(nn.Module):
         """drop_masks=(m1,m2): optional already-scaled dropout multipliers [B,256,N] (parity tests)."""
         if not x.is_cuda:
             raise RuntimeError("hpcs_amd.VN_DGCNN_partseg runs on a HIP device only (no CPU fallback)")
+        with batch_counters():            # one multi-tensor add for all BatchNorm step counters
+            return self._forward(x, l, drop_masks)
+
+    def _forward(self, x, l, drop_masks):
         B, N = x.size(0), x.size(2)
         h = x.unsqueeze(1)
 
@@ -137,7 +141,7 @@ class VN_DGCNN_partseg(nn.Module):
         m1 = self._drop_mask(y8, self.dropout, None if drop_masks is None else drop_masks[0])
         hh = ops.bn_act(y8, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training, 0.2, m1)
         if self.training:
-            bn.num_batches_tracked.add_(1)
+            bump(bn)
         m2 = self._drop_mask(hh, self.dropout, None if drop_masks is None else drop_masks[1])
         hh = self._head(self.conv9, hh, mask=m2)
         hh = self._head(self.conv10, hh)

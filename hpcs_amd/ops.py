@@ -123,6 +123,24 @@ def _grad_sink(spec):
     return p.grad[index]
 
 
+def _bn_grads(ctx_params, red, C, needs_gamma, needs_beta):
+    """(ggamma, gbeta) from the fp64 reduction red = [sum_beta(C) | sum_gamma(C)]: added into .grad on the side stream
+    inside deferred_weight_grads(), else returned to autograd as fp32."""
+    gamma, beta = ctx_params
+    ggamma = gbeta = None
+    sg = _grad_sink((gamma, ...)) if (needs_gamma and gamma is not None) else None
+    sb = _grad_sink((beta, ...)) if (needs_beta and beta is not None) else None
+    if sg is not None and sb is not None:
+        def work():
+            sg.add_(red[C:])
+            sb.add_(red[:C])
+        _on_side_stream(work, (red,))
+    else:
+        ggamma = red[C:].float() if needs_gamma else None
+        gbeta = red[:C].float() if needs_beta else None
+    return ggamma, gbeta
+
+
 def _on_side_stream(work, keep_alive):
     main = torch.cuda.current_stream()
     side = _SideWGrad.stream
@@ -249,6 +267,7 @@ class VNLayerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, Wf, Wd, gamma, beta, rmean, rvar, training, slope, pool_k, flags, xconst):
         ctx.wparams = (Wf, Wd)
+        ctx.bnparams = (gamma, beta)
         x = _f32c(x)
         B, Cin = x.shape[0], x.shape[1]
         L = x[0, 0, 0].numel()
@@ -341,8 +360,7 @@ class VNLayerFn(torch.autograd.Function):
                 gW = gWcat[:Cout]
                 gWd = gWcat[Cout:] if Cd else None
         if flags & VN_BN:
-            gbeta = red[:Cout].float()
-            ggamma = red[Cout:].float()
+            ggamma, gbeta = _bn_grads(ctx.bnparams, red, Cout, ctx.needs_input_grad[3], ctx.needs_input_grad[4])
         return gx, gW, gWd, ggamma, gbeta, None, None, None, None, None, None, gxc
 
 
@@ -426,6 +444,7 @@ class BnActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y, gamma, beta, rmean, rvar, training, slope, mask):
+        ctx.bnparams = (gamma, beta)
         y = _f32c(y)
         B, C = y.shape[0], y.shape[1]
         L = y[0, 0].numel()
@@ -452,7 +471,8 @@ class BnActFn(torch.autograd.Function):
         call("hpcs_bn_act_bwd_reduce", y, g, mean, rstd, gamma, beta, mask, B, C, L, slope, red)
         gy = torch.empty_like(y)
         call("hpcs_bn_act_bwd_apply", y, g, mean, rstd, gamma, beta, mask, red, 1 if training else 0, B, C, L, slope, gy)
-        return gy, red[C:].float(), red[:C].float(), None, None, None, None, None
+        ggamma, gbeta = _bn_grads(ctx.bnparams, red, C, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
+        return gy, ggamma, gbeta, None, None, None, None, None
 
 
 def bn_act(y, gamma, beta, rmean, rvar, training, slope=0.2, mask=None):
