@@ -134,8 +134,7 @@ class VN_DGCNN_partseg(nn.Module):
 
         W8 = self.conv8[0].weight[:, :, 0]
         W8p, gc = self.conv8[0].weight, self._glob_ch
-        bias8 = ops.chan_mix(vec.unsqueeze(-1), W8[:, :gc],
-                             sink=(W8p, (slice(None), slice(0, gc), 0))).view(B, -1)        # [B,256]
+        bias8 = ops.row_linear(vec, W8[:, :gc], sink=(W8p, (slice(None), slice(0, gc), 0)))  # [B,256]
         y8 = ops.chan_mix(loc, W8[:, gc:], bias8, sink=(W8p, (slice(None), slice(gc, None), 0)))
         bn = self.bn8
         m1 = self._drop_mask(y8, self.dropout, None if drop_masks is None else drop_masks[0])

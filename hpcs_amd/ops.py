@@ -22,6 +22,12 @@ def _f32c(t):
     return t.contiguous() if t.dtype == torch.float32 else t.float().contiguous()
 
 
+def _f32c_keep(W):
+    """fp32 weight with a contiguous last dim (parameters already are: no copy, so column slices alias them)."""
+    W = W if W.dtype == torch.float32 else W.float()
+    return W if W.stride(-1) == 1 else W.contiguous()
+
+
 def _pad4(n):
     return (n + 3) // 4 * 4
 
@@ -245,6 +251,68 @@ def chan_mix(x, W, rowbias=None, sink=None):
     return ChanMixFn.apply(x, W, rowbias, sink)
 
 
+# ------------------------------------------------------------------------------------------------ row-vector linear
+def _nt_into(G, ldg, X, ldx, R, M, K, out, ldo, accumulate=False):
+    """out[R, M] (row stride ldo) = G[R, K] @ X[M, K]^T, reduction over the contiguous index (split over workgroups)."""
+    nbytes = call("hpcs_gemm_nt_workspace", R, M, K, 1, 1)
+    ws = torch.empty(nbytes // 4 + 4, device=G.device, dtype=torch.float32)
+    call("hpcs_gemm_nt", G.data_ptr(), ldg, 0, 0, X.data_ptr(), ldx, 0, 0, R, M, K, 1, 1, out.data_ptr(), ldo,
+         1 if accumulate else 0, ws, nbytes)
+    return out
+
+
+def _rowmajor_view(W):
+    """(tensor, row stride) for a 2-D weight view whose last dim is contiguous (column slices stay un-copied)."""
+    if W.dim() != 2 or W.stride(1) != 1:
+        W = W.contiguous()
+    return W, W.stride(0)
+
+
+class RowLinearFn(torch.autograd.Function):
+    """out[R, M] = vec[R, K] @ W[M, K]^T for a FEW rows R (one per cloud): the N-constant channels of conv8 enter as a
+    [B,256] row bias (vn_dgcnn_partseg.py:91-96).  As a per-cloud channel mix this is 32 GEMMs with ONE column each; in
+    this orientation it is a single split-reduction GEMM, and both gradients are single GEMMs too."""
+
+    @staticmethod
+    def forward(ctx, vec, W, sink=None):
+        vec = _f32c(vec)
+        W, ldw = _rowmajor_view(W if W.dtype == torch.float32 else W.float())
+        R, K = vec.shape
+        M = W.shape[0]
+        out = torch.empty(R, M, device=vec.device, dtype=torch.float32)
+        _nt_into(vec, K, W, ldw, R, M, K, out, M)
+        ctx.save_for_backward(vec, W)
+        ctx.sink = sink
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        vec, W = ctx.saved_tensors
+        g = _f32c(g)
+        R, K = vec.shape
+        M, ldw = W.shape[0], W.stride(0)
+        gvec = gW = None
+        if ctx.needs_input_grad[0]:
+            gT = g.t().contiguous()                                   # [M, R] = At of the data-gradient GEMM
+            gvec = torch.empty(R, K, device=g.device, dtype=torch.float32)
+            call("hpcs_gemm_tn", gT, R, W.data_ptr(), ldw, 0, 0, gvec, K, 0, 0, R, K, M, 1, 1, None, 0)
+        if ctx.needs_input_grad[1]:
+            dst = _grad_sink(ctx.sink)
+            if dst is not None and dst.stride(-1) == 1:
+                def work():             # dW[M, K] += g^T vec, straight into the parameter's gradient
+                    call("hpcs_gemm_tn", g, M, vec, K, 0, 0, dst.data_ptr(), dst.stride(0), 0, 0, M, K, R, 1, 1, None, 1)
+                _on_side_stream(work, (g, vec))
+            else:
+                gW = torch.empty(M, K, device=g.device, dtype=torch.float32)
+                call("hpcs_gemm_tn", g, M, vec, K, 0, 0, gW, K, 0, 0, M, K, R, 1, 1, None, 0)
+        return gvec, gW, None
+
+
+def row_linear(vec, W, sink=None):
+    _need_cuda(vec, W)
+    return RowLinearFn.apply(vec, W, sink)
+
+
 # ------------------------------------------------------------------------------------------------ a3
 def _gemm_inner3(W, x, B, K, L, rowbias3):
     """PD[b,:,a,:] = W @ x[b,:,a,:] + rowbias3[b,a,:]  -- walks a [B,K,3,L] tensor as 3B matrices of L columns."""
@@ -276,19 +344,26 @@ class VNLayerFn(torch.autograd.Function):
         Wd_ = Wd if Cd else None
         Ctot = Cout + Cd
         Cc = 0
-        WcP = None
+        xcT = None
+        ctx.wversions = (Wf._version, None if Wd is None else Wd._version)
         if xconst is not None:
             xconst = _f32c(xconst)
             Cc = xconst.shape[1]
             WxP = PreparedW(Wf[:, :Cin], None if Wd_ is None else Wd_[:, :Cin])      # column slices: no copies
-            WcP = PreparedW(Wf[:, Cin:], None if Wd_ is None else Wd_[:, Cin:])
-            bias = gemm_WX(WcP, xconst, B, Cc, 3).view(B, Ctot, 3).permute(0, 2, 1).contiguous()     # [B,3,Ctot]
+            # bias[(b,xyz), :] = [Wf_c; Wd_c] xconst[b, :, xyz]: ONE split-reduction GEMM over the 3B rows per weight
+            # block (as a per-cloud channel mix it would be B GEMMs of 3 columns each)
+            xcT = xconst.permute(0, 2, 1).contiguous()                                # [B,3,Cc]
+            bias = torch.empty(B, 3, Ctot, device=x.device, dtype=torch.float32)
+            Wfc, ldf = _rowmajor_view(_f32c_keep(Wf)[:, Cin:])
+            _nt_into(xcT, Cc, Wfc, ldf, 3 * B, Cout, Cc, bias, Ctot)
+            if Cd:
+                Wdc, ldd = _rowmajor_view(_f32c_keep(Wd_)[:, Cin:])
+                _nt_into(xcT, Cc, Wdc, ldd, 3 * B, Cd, Cc, bias[:, :, Cout:], Ctot)
             PD = _gemm_inner3(WxP, x, B, Cin, L, bias)
         else:
             WxP = PreparedW(Wf, Wd_)
             PD = gemm_WX(WxP, x, B, Cin, 3 * L)
         Wx = WxP.Wp
-        Wc = None if WcP is None else WcP.Wp
         dev = x.device
         mean = rstd = None
         if flags & VN_BN:
@@ -304,13 +379,13 @@ class VNLayerFn(torch.autograd.Function):
         else:
             out = torch.empty(B, Cout, *x.shape[2:], device=dev)
         call("hpcs_vn_apply_fwd", PD, mean, rstd, gamma, beta, B, Cout, Cd, L, pool_k, slope, flags, out)
-        ctx.save_for_backward(x, Wx, Wc, xconst, PD, mean, rstd, gamma, beta)
+        ctx.save_for_backward(x, Wx, xcT, PD, mean, rstd, gamma, beta)
         ctx.cfg = (B, Cin, Cc, Cout, Cd, L, pool_k, slope, flags, bool(training))
         return out
 
     @staticmethod
     def backward(ctx, g):
-        x, Wx, Wc, xconst, PD, mean, rstd, gamma, beta = ctx.saved_tensors
+        x, Wx, xcT, PD, mean, rstd, gamma, beta = ctx.saved_tensors
         B, Cin, Cc, Cout, Cd, L, pool_k, slope, flags, training = ctx.cfg
         g = _f32c(g)
         dev = g.device
@@ -328,19 +403,32 @@ class VNLayerFn(torch.autograd.Function):
             call("hpcs_gemm_tn", Wx, Wx.shape[1], GPD, 3 * L, Ctot * 3 * L, 0, gx, 3 * L, Cin * 3 * L, 0, Cin, 3 * L, Ctot, B, 1,
                  None, 0)
             gx = gx.view_as(x)
-        S = None
+        ST = None
         if Cc:
             S = torch.empty(B, Ctot, 3, device=dev)
             call("hpcs_rowsum", GPD, B * Ctot * 3, L, 1.0, S)
+            ST = S.permute(0, 2, 1).contiguous()                              # [(b,xyz), Ctot]
             if ctx.needs_input_grad[11]:
-                gxc = torch.empty(B * Cc * 3, device=dev)
-                call("hpcs_gemm_tn", Wc, Wc.shape[1], S, 3, Ctot * 3, 0, gxc, 3, Cc * 3, 0, Cc, 3, Ctot, B, 1, None, 0)
-                gxc = gxc.view(B, Cc, 3)
+                # gxc[(b,xyz), :] = ST [Wf_c; Wd_c]: two accumulating GEMMs (one per weight block), At = ST^T
+                Wf_, Wd_ = ctx.wparams          # the constant-channel columns are read from the live weights
+                if (Wf_._version, None if Wd_ is None else Wd_._version) != ctx.wversions:
+                    raise RuntimeError("VNLayerFn: weights were modified in place between forward and backward")
+                STt = ST.view(3 * B, Ctot).t().contiguous()                   # [Ctot, 3B]
+                gxcT = torch.empty(3 * B, Cc, device=dev)
+                Wfc, ldf = _rowmajor_view(_f32c_keep(Wf_)[:, Cin:])
+                call("hpcs_gemm_tn", STt, 3 * B, Wfc.data_ptr(), ldf, 0, 0, gxcT, Cc, 0, 0, 3 * B, Cc, Cout, 1, 1, None, 0)
+                if Cd:
+                    Wdc, ldd = _rowmajor_view(_f32c_keep(Wd_)[:, Cin:])
+                    call("hpcs_gemm_tn", STt[Cout:], 3 * B, Wdc.data_ptr(), ldd, 0, 0, gxcT, Cc, 0, 0, 3 * B, Cc, Cd, 1, 1,
+                         None, 1)
+                gxc = gxcT.view(B, 3, Cc).permute(0, 2, 1)
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             def weight_grads():
                 gWcat = gemm_GXt(GPD, x, B, Ctot, Cin, 3 * L)
-                if Cc:
-                    gWcat = torch.cat([gWcat, gemm_GXt(S, xconst, B, Ctot, Cc, 3)], dim=1)
+                if Cc:                  # dWc[Ctot, Cc] = ST^T xcT: reduction over the 3B rows
+                    gWc = torch.empty(Ctot, Cc, device=dev)
+                    call("hpcs_gemm_tn", ST, Ctot, xcT, Cc, 0, 0, gWc, Cc, 0, 0, Ctot, Cc, 3 * B, 1, 1, None, 0)
+                    gWcat = torch.cat([gWcat, gWc], dim=1)
                 return gWcat
 
             Wf_, Wd_ = ctx.wparams
@@ -354,7 +442,7 @@ class VNLayerFn(torch.autograd.Function):
                         sink_f.add_(gWcat[:Cout])
                     if sink_d is not None:
                         sink_d.add_(gWcat[Cout:])
-                _on_side_stream(work, (GPD, x, S, xconst))
+                _on_side_stream(work, (GPD, x, ST, xcT))
             else:
                 gWcat = weight_grads()
                 gW = gWcat[:Cout]

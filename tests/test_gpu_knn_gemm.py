@@ -94,3 +94,23 @@ def test_gemm_nt(M, Kx, Nc, nb):
     _lib.call("hpcs_gemm_nt", G.to(dev), Nc, M * Nc, 0, X.to(dev), Nc, Kx * Nc, 0, M, Kx, Nc, nb, 1, dW, Kx, 1, ws, nbytes)
     want = torch.einsum("bmc,bkc->mk", G.double(), X.double()) + 3.0
     torch.testing.assert_close(dW.cpu().double(), want, rtol=1e-5, atol=2e-6 * float(want.abs().max()) * np.sqrt(Nc * nb))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,K,M,ld", [(32, 2110, 256, 2299), (96, 341, 682, 682), (5, 7, 3, 9)])
+def test_row_linear_matches_fp64(R, K, M, ld):
+    """ops.row_linear: out = vec @ W^T on a column slice of a wider weight, forward and both gradients."""
+    from hpcs_amd import ops
+    torch.manual_seed(3)
+    Wfull = torch.randn(M, ld, device="cuda", requires_grad=True)
+    vec = torch.randn(R, K, device="cuda", requires_grad=True)
+    out = ops.row_linear(vec, Wfull[:, ld - K:])
+    g = torch.randn_like(out)
+    out.backward(g)
+    ref = vec.detach().double() @ Wfull.detach()[:, ld - K:].double().t()
+    assert torch.allclose(out.double(), ref, rtol=1e-5, atol=1e-5 * float(ref.abs().max()))
+    gv = g.double() @ Wfull.detach()[:, ld - K:].double()
+    gw = g.double().t() @ vec.detach().double()
+    assert torch.allclose(vec.grad.double(), gv, rtol=1e-5, atol=1e-5 * float(gv.abs().max()))
+    assert torch.allclose(Wfull.grad[:, ld - K:].double(), gw, rtol=1e-5, atol=1e-5 * float(gw.abs().max()))
+    assert float(Wfull.grad[:, :ld - K].abs().max()) == 0.0 if ld > K else True
