@@ -134,6 +134,69 @@ __global__ __launch_bounds__(WM* WN * 64, 4) void gemm_tn_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Small problems (a handful of MFMA tiles in total: row biases, [3B x C] frames): the tiled kernel would run on two
+// or three workgroups and is pure latency.  A workgroup owns 8 output rows x 32 columns; eight lanes per column split
+// the reduction (k = s, s+8, ...) and every B element fetched from L2 feeds the 8 rows; the partial sums meet in a
+// 3-step butterfly.
+constexpr int SMALL_RB = 8;
+__global__ __launch_bounds__(256) void gemm_tn_small_kernel(
+    const float* __restrict__ At, int lda, const float* __restrict__ Bm, int ldb, int64_t sBo, int64_t sBi,
+    float* __restrict__ C, int ldc, int64_t sCo, int64_t sCi, int M, int Nc, int K, int n_inner,
+    const float* __restrict__ rowbias, int accumulate, int colBlocks, int rowBlocks) {
+    const int cb = blockIdx.x % colBlocks;
+    const int t1 = blockIdx.x / colBlocks;
+    const int row0 = (t1 % rowBlocks) * SMALL_RB, batch = t1 / rowBlocks;
+    const int s = threadIdx.x & 7;
+    const int col = cb * 32 + (threadIdx.x >> 3);
+    const bool live = col < Nc;
+    const int bo = batch / n_inner, bi = batch % n_inner;
+    const float* Bp = Bm + bo * sBo + bi * sBi + (live ? col : 0);
+    float acc[SMALL_RB];
+#pragma unroll
+    for (int r = 0; r < SMALL_RB; ++r) acc[r] = 0.f;
+    int k = s;
+    for (; k + 8 < K; k += 16) {
+        const float b0 = Bp[(int64_t)k * ldb], b1 = Bp[(int64_t)(k + 8) * ldb];
+        const float* A0 = At + (int64_t)k * lda + row0;
+        const float* A1 = A0 + (int64_t)8 * lda;
+        float a0[SMALL_RB], a1[SMALL_RB];
+#pragma unroll
+        for (int r = 0; r < SMALL_RB; ++r) {
+            const bool in = row0 + r < M;
+            a0[r] = in ? A0[r] : 0.f;
+            a1[r] = in ? A1[r] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < SMALL_RB; ++r) acc[r] = fmaf(a1[r], b1, fmaf(a0[r], b0, acc[r]));
+    }
+    for (; k < K; k += 8) {
+        const float b0 = Bp[(int64_t)k * ldb];
+        const float* A0 = At + (int64_t)k * lda + row0;
+#pragma unroll
+        for (int r = 0; r < SMALL_RB; ++r) acc[r] = fmaf(row0 + r < M ? A0[r] : 0.f, b0, acc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < SMALL_RB; ++r) {
+        float v = acc[r];
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 4, 64);
+        acc[r] = v;
+    }
+    if (!live) return;
+    // lane s finishes row row0 + s
+    float mine = acc[0];
+#pragma unroll
+    for (int r = 1; r < SMALL_RB; ++r) mine = s == r ? acc[r] : mine;
+    const int row = row0 + s;
+    if (row >= M) return;
+    if (rowbias) mine += rowbias[(int64_t)batch * M + row];
+    float* dst = C + bo * sCo + bi * sCi + (int64_t)row * ldc + col;
+    if (accumulate) mine += *dst;
+    *dst = mine;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // weight-grad: both operands have the reduction index (columns) contiguous.  LDS rows padded to BKC+1 so the
 // 32 lanes of an operand fetch (32 different rows, same column) hit 32 different banks.
 template <int BM, int BN, int BKC, int WM, int WN>
@@ -279,6 +342,17 @@ NtPlan nt_plan(int M, int Kx, int Nc, int n_batch) {
     p.tilesM = hpcs_cdiv(M, p.tile);
     p.tilesK = hpcs_cdiv(Kx, p.tile);
     p.chunk = 2048;
+    {   // short reductions (row-oriented bias GEMMs): shrink the chunk until ~512 workgroups share the columns
+        const long tiles = (long)p.tilesM * p.tilesK;
+        const long units0 = (long)n_batch * hpcs_cdiv(Nc, p.chunk);
+        if (units0 * tiles < 256) {
+            const long target_units = 512 / tiles > 0 ? 512 / tiles : 1;
+            long c = hpcs_cdiv((int64_t)Nc * n_batch, target_units);
+            c = (c + 31) / 32 * 32;
+            if (c < 64) c = 64;
+            if (c < p.chunk) p.chunk = (int)c;
+        }
+    }
     p.units_per_batch = hpcs_cdiv(Nc, p.chunk);
     const long units = (long)n_batch * p.units_per_batch;
     long want = 2048 / ((long)p.tilesM * p.tilesK);
@@ -327,6 +401,18 @@ extern "C" int hpcs_gemm_tn(const float* At, int lda, const float* Bm, int ldb, 
     const int vecA = (lda % 4 == 0) && aligned16(At);
     const int vecB = (ldb % 4 == 0) && (strideB_o % 4 == 0) && (strideB_i % 4 == 0) && aligned16(Bm);
     const int nb = n_outer * n_inner;
+    {   // fewer than 32 tiles of 128x128 over all batches and a short enough reduction: the per-element kernel
+        const long tiles = (long)hpcs_cdiv(M, 128) * hpcs_cdiv(Nc, 128) * nb;
+        if (tiles < 32 && Nc >= 16 && (long)K <= 4096) {
+            const int colBlocks = hpcs_cdiv(Nc, 32), rowBlocks = hpcs_cdiv(M, SMALL_RB);
+            const long blocks = (long)colBlocks * rowBlocks * nb;
+            hipLaunchKernelGGL(gemm_tn_small_kernel, dim3((unsigned)blocks), dim3(256), 0, st, At, lda, Bm, ldb, strideB_o,
+                               strideB_i, C, ldc, strideC_o, strideC_i, M, Nc, K, n_inner, rowbias, accumulate, colBlocks,
+                               rowBlocks);
+            HPCS_CHECK_LAUNCH();
+            return HPCS_OK;
+        }
+    }
     if (M > 64) {
         constexpr int BM = 128, BN = 128, BK = 16;
         const int tm = hpcs_cdiv(M, BM), tn = hpcs_cdiv(Nc, BN);

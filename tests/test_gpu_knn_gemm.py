@@ -51,8 +51,11 @@ def test_knn_errors():
         _lib.call("hpcs_knn", torch.zeros(1, 3, 16), 1, 3, 16, 4, idx, None, 0)   # CPU tensor: no fallback
 
 
+# shapes with < 32 MFMA tiles take the per-element kernel, the larger ones the 64x128 / 128x128 MFMA kernels
 @pytest.mark.parametrize("M,K,Nc,nb", [(21, 2, 300, 3), (42, 42, 1024, 2), (341, 63, 3 * 256, 2),
-                                       (682, 682, 3 * 128, 2), (256, 189, 1024, 2), (3, 170, 96, 4), (64, 16, 1, 5)])
+                                       (682, 682, 3 * 128, 2), (256, 189, 1024, 2), (3, 170, 96, 4), (64, 16, 1, 5),
+                                       (42, 42, 2560, 2), (21, 2, 2600, 3), (341, 63, 1536, 4), (682, 682, 768, 2),
+                                       (256, 189, 2051, 2), (96, 341, 341, 1)])
 def test_gemm_tn(M, K, Nc, nb):
     W = det_uniform((M, K), 200 + M)           # weights [M,K]
     X = det_normalish((nb, K, Nc), 300 + K)
