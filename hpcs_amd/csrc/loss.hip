@@ -28,6 +28,25 @@ __device__ __forceinline__ float sub_sum(float v) {
     return v;
 }
 
+// ---- 8-lane group data movement on the VALU (DPP): no LDS round trip, unlike __shfl's ds_bpermute ----------------
+// All of these must run with every lane of the wave active (uniform control flow).
+template <int C>   // value held by lane C (0..3) of each 8-lane group -> all 8 lanes of the group
+__device__ __forceinline__ int grp_bcast(int x) {
+    const int t = __builtin_amdgcn_update_dpp(x, x, C | (C << 2) | (C << 4) | (C << 6), 0xF, 0xF, false);   // quad_perm
+    return __builtin_amdgcn_update_dpp(t, t, 0x114, 0xF, 0xA, false);        // row_shr:4 into the upper quads only
+}
+template <int C>
+__device__ __forceinline__ float grp_bcast(float x) { return __int_as_float(grp_bcast<C>(__float_as_int(x))); }
+// lane s <- lane s+1 (the group's last lane receives its neighbour group's first value or keeps its own: unused)
+__device__ __forceinline__ int grp_shift_down(int x) { return __builtin_amdgcn_update_dpp(x, x, 0x101, 0xF, 0xF, false); }
+// sum over the 8 lanes of a group, result in all of them: xor-1, xor-2 inside quads, then the mirrored other quad
+__device__ __forceinline__ float grp_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    return v;
+}
+
 __device__ __forceinline__ uint64_t mix64(uint64_t z) {
     z += 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -597,7 +616,9 @@ __global__ __launch_bounds__(SB_THREADS) void hyphc_sampled_kernel(
         const int cpos_own = (c == cb && pr_own < RC) ? pr_own : -1;       // slot in the LDS positive table, or -1
 
         // ---- the group walks its 8 triplets; rows of the next one are prefetched during the math -------------------
-        int ia = __shfl(ia_own, sub0, 64), ip = __shfl(ip_own, sub0, 64), in = __shfl(in_own, sub0, 64);
+        // per-triplet values travel down the group by one lane per step, so every broadcast has a constant source lane
+        int ia_sh = ia_own, ip_sh = ip_own, in_sh = in_own, lv_sh = (int)lv_own, cp_sh = cpos_own;
+        int ia = grp_bcast<0>(ia_sh), ip = grp_bcast<0>(ip_sh), in = grp_bcast<0>(in_sh);
         float av[EPL], pv[EPL], nv[EPL], av2[EPL], pv2[EPL], nv2[EPL];
         IO::load(xn, E, ia, s, av);
         IO::load(xn, E, ip, s, pv);
@@ -606,15 +627,15 @@ __global__ __launch_bounds__(SB_THREADS) void hyphc_sampled_kernel(
         for (int j8 = 0; j8 < SUB; ++j8) {
             int ia2 = 0, ip2 = 0, in2 = 0;
             if (j8 + 1 < SUB) {
-                ia2 = __shfl(ia_own, sub0 + j8 + 1, 64);
-                ip2 = __shfl(ip_own, sub0 + j8 + 1, 64);
-                in2 = __shfl(in_own, sub0 + j8 + 1, 64);
+                ia2 = grp_bcast<1>(ia_sh);
+                ip2 = grp_bcast<1>(ip_sh);
+                in2 = grp_bcast<1>(in_sh);
                 IO::load(xn, E, ia2, s, av2);
                 IO::load(xn, E, ip2, s, pv2);
                 IO::load(xn, E, in2, s, nv2);
             }
-            bool live = __shfl((int)lv_own, sub0 + j8, 64) != 0;
-            const int cpos = __shfl(cpos_own, sub0 + j8, 64);
+            bool live = grp_bcast<0>(lv_sh) != 0;
+            const int cpos = grp_bcast<0>(cp_sh);
             float d1 = 0.f, d2 = 0.f, d3 = 0.f;
 #pragma unroll
             for (int j = 0; j < EPL; ++j) {
@@ -622,9 +643,9 @@ __global__ __launch_bounds__(SB_THREADS) void hyphc_sampled_kernel(
                 d2 += av[j] * nv[j];
                 d3 += pv[j] * nv[j];
             }
-            d1 = sub_sum(d1);
-            d2 = sub_sum(d2);
-            d3 = sub_sum(d3);
+            d1 = grp_sum(d1);
+            d2 = grp_sum(d2);
+            d3 = grp_sum(d3);
             if (kind >= 0) {
                 const float tm = 0.5f * (1.f + d1) - 0.5f * (1.f + d2);
                 live = live && keep_rule(tm, margin, kind);
@@ -633,10 +654,10 @@ __global__ __launch_bounds__(SB_THREADS) void hyphc_sampled_kernel(
             const float my_dot = s == 0 ? d1 : (s == 1 ? d2 : d3);
             const LcaF L = lca_of_dot(sc, my_dot);
             const float dsc = L.d * inv_t;
-            const float q0 = __shfl(dsc, sub0, 64), q1 = __shfl(dsc, sub0 + 1, 64), q2 = __shfl(dsc, sub0 + 2, 64);
+            const float q0 = grp_bcast<0>(dsc), q1 = grp_bcast<1>(dsc), q2 = grp_bcast<2>(dsc);
             const float mx = fmaxf(q0, fmaxf(q1, q2));
             const float ex = __expf(dsc - mx);
-            const float e0 = __shfl(ex, sub0, 64), e1 = __shfl(ex, sub0 + 1, 64), e2 = __shfl(ex, sub0 + 2, 64);
+            const float e0 = grp_bcast<0>(ex), e1 = grp_bcast<1>(ex), e2 = grp_bcast<2>(ex);
             const float w0 = 0.5f * (1.f + d1), w1 = 0.5f * (1.f + d2), w2 = 0.5f * (1.f + d3);
             const float den = e0 + e1 + e2;
             const float wbar = (e0 * w0 + e1 * w1 + e2 * w2) / den;
@@ -647,8 +668,7 @@ __global__ __launch_bounds__(SB_THREADS) void hyphc_sampled_kernel(
                 const float gd = -(sm * (my_w - wbar)) * inv_t;
                 const float gw = (1.f - sm) + gd * L.dd_dw;                      // unscaled: upstream/kept applied later
                 if (live && s < 3 && s_live) acc_gs += (double)(gd * L.dd_ds);
-                const float c0 = 0.5f * __shfl(gw, sub0, 64), c1 = 0.5f * __shfl(gw, sub0 + 1, 64),
-                            c2 = 0.5f * __shfl(gw, sub0 + 2, 64);
+                const float c0 = 0.5f * grp_bcast<0>(gw), c1 = 0.5f * grp_bcast<1>(gw), c2 = 0.5f * grp_bcast<2>(gw);
                 if (live) {
                     if (ia != cur) {
                         if (cur >= 0) {
@@ -677,15 +697,22 @@ __global__ __launch_bounds__(SB_THREADS) void hyphc_sampled_kernel(
                 for (int j = 0; j < EPL; ++j) slab[gi * LD + s * EPL + j] = live ? c1 * av[j] + c2 * pv[j] : 0.f;
                 __builtin_amdgcn_s_waitcnt(0xC07F);
                 constexpr int RPI = 64 / E;
+                const int in_live = live ? in : -1;                  // uniform inside a group: read through v_readlane
 #pragma unroll
                 for (int r = 0; r < EPL; ++r) {
                     const int tw = r * RPI + lane / E, e = lane % E;
-                    const int rn = __shfl(in, tw * SUB, 64);
-                    const bool lv = __shfl((int)live, tw * SUB, 64) != 0;
-                    if (lv) atomicAdd(gxn + (unsigned)(rn * E + e), slab[tw * LD + e]);
+                    int rn = __builtin_amdgcn_readlane(in_live, (r * RPI) * SUB);
+#pragma unroll
+                    for (int q = 1; q < RPI; ++q) {
+                        const int v = __builtin_amdgcn_readlane(in_live, (r * RPI + q) * SUB);
+                        rn = lane / E == q ? v : rn;
+                    }
+                    if (rn >= 0) atomicAdd(gxn + (unsigned)(rn * E + e), slab[tw * LD + e]);
                 }
             }
             ia = ia2; ip = ip2; in = in2;
+            ia_sh = grp_shift_down(ia_sh); ip_sh = grp_shift_down(ip_sh); in_sh = grp_shift_down(in_sh);
+            lv_sh = grp_shift_down(lv_sh); cp_sh = grp_shift_down(cp_sh);
 #pragma unroll
             for (int j = 0; j < EPL; ++j) { av[j] = av2[j]; pv[j] = pv2[j]; nv[j] = nv2[j]; }
         }
