@@ -541,9 +541,12 @@ __global__ __launch_bounds__(SB_THREADS) void hyphc_sampled_kernel(
     constexpr int E = 8 * EPL;
     using IO = RowIO<EPL, true>;
     constexpr int LD = E + 8;
+    // positive table: row stride TS = E + 8 and element (lane s, j) at j*8 + s, so one ds_add_f32 wave-instruction
+    // (8 groups x 8 lanes, same j) spreads over the banks instead of stacking 8 deep on every fourth one
+    constexpr int TS = E + 8;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* cache = smem;                                            // [RC][E]   (GRAD only)
-    float* stage = smem + (GRAD ? (size_t)RC * E : 0);              // [waves][8][LD] negative-row transposition slab
+    float* cache = smem;                                            // [RC][TS]  (GRAD only)
+    float* stage = smem + (GRAD ? (size_t)RC * TS : 0);             // [waves][8][LD] negative-row transposition slab
     __shared__ double red[16];
     __shared__ int cb_sh[3];
 
@@ -565,7 +568,7 @@ __global__ __launch_bounds__(SB_THREADS) void hyphc_sampled_kernel(
         cb_sh[2] = offsets[cb + 1] - offsets[cb];
     }
     if (GRAD)
-        for (int i = threadIdx.x; i < RC * E; i += SB_THREADS) cache[i] = 0.f;
+        for (int i = threadIdx.x; i < RC * TS; i += SB_THREADS) cache[i] = 0.f;
     __syncthreads();
     const int cb = cb_sh[0];
 
@@ -615,61 +618,88 @@ __global__ __launch_bounds__(SB_THREADS) void hyphc_sampled_kernel(
         if (a_dbg && lv_own) { a_dbg[tl] = ia_own; p_dbg[tl] = ip_own; n_dbg[tl] = in_own; }
         const int cpos_own = (c == cb && pr_own < RC) ? pr_own : -1;       // slot in the LDS positive table, or -1
 
-        // ---- the group walks its 8 triplets; rows of the next one are prefetched during the math -------------------
-        // per-triplet values travel down the group by one lane per step, so every broadcast has a constant source lane
-        int ia_sh = ia_own, ip_sh = ip_own, in_sh = in_own, lv_sh = (int)lv_own, cp_sh = cpos_own;
-        int ia = grp_bcast<0>(ia_sh), ip = grp_bcast<0>(ip_sh), in = grp_bcast<0>(in_sh);
+        // ---- phase A: the group walks its 8 triplets for the three dot products; lane j keeps those of triplet j.
+        // Per-triplet values travel down the group by one lane per step, so every broadcast has a constant source lane;
+        // the rows of the next triplet are in flight during the math of the current one.
         float av[EPL], pv[EPL], nv[EPL], av2[EPL], pv2[EPL], nv2[EPL];
-        IO::load(xn, E, ia, s, av);
-        IO::load(xn, E, ip, s, pv);
-        IO::load(xn, E, in, s, nv);
+        float D1 = 0.f, D2 = 0.f, D3 = 0.f;
+        {
+            int ia_sh = ia_own, ip_sh = ip_own, in_sh = in_own;
+            IO::load(xn, E, grp_bcast<0>(ia_sh), s, av);
+            IO::load(xn, E, grp_bcast<0>(ip_sh), s, pv);
+            IO::load(xn, E, grp_bcast<0>(in_sh), s, nv);
 #pragma unroll 1
-        for (int j8 = 0; j8 < SUB; ++j8) {
-            int ia2 = 0, ip2 = 0, in2 = 0;
-            if (j8 + 1 < SUB) {
-                ia2 = grp_bcast<1>(ia_sh);
-                ip2 = grp_bcast<1>(ip_sh);
-                in2 = grp_bcast<1>(in_sh);
-                IO::load(xn, E, ia2, s, av2);
-                IO::load(xn, E, ip2, s, pv2);
-                IO::load(xn, E, in2, s, nv2);
-            }
-            bool live = grp_bcast<0>(lv_sh) != 0;
-            const int cpos = grp_bcast<0>(cp_sh);
-            float d1 = 0.f, d2 = 0.f, d3 = 0.f;
+            for (int j8 = 0; j8 < SUB; ++j8) {
+                if (j8 + 1 < SUB) {
+                    IO::load(xn, E, grp_bcast<1>(ia_sh), s, av2);
+                    IO::load(xn, E, grp_bcast<1>(ip_sh), s, pv2);
+                    IO::load(xn, E, grp_bcast<1>(in_sh), s, nv2);
+                }
+                float d1 = 0.f, d2 = 0.f, d3 = 0.f;
 #pragma unroll
-            for (int j = 0; j < EPL; ++j) {
-                d1 += av[j] * pv[j];
-                d2 += av[j] * nv[j];
-                d3 += pv[j] * nv[j];
+                for (int j = 0; j < EPL; ++j) {
+                    d1 += av[j] * pv[j];
+                    d2 += av[j] * nv[j];
+                    d3 += pv[j] * nv[j];
+                }
+                d1 = grp_sum(d1);
+                d2 = grp_sum(d2);
+                d3 = grp_sum(d3);
+                const bool mine = s == j8;
+                D1 = mine ? d1 : D1;
+                D2 = mine ? d2 : D2;
+                D3 = mine ? d3 : D3;
+                ia_sh = grp_shift_down(ia_sh); ip_sh = grp_shift_down(ip_sh); in_sh = grp_shift_down(in_sh);
+#pragma unroll
+                for (int j = 0; j < EPL; ++j) { av[j] = av2[j]; pv[j] = pv2[j]; nv[j] = nv2[j]; }
             }
-            d1 = grp_sum(d1);
-            d2 = grp_sum(d2);
-            d3 = grp_sum(d3);
-            if (kind >= 0) {
-                const float tm = 0.5f * (1.f + d1) - 0.5f * (1.f + d2);
-                live = live && keep_rule(tm, margin, kind);
-            }
-            if (live && s == 0) ++kept;
-            const float my_dot = s == 0 ? d1 : (s == 1 ? d2 : d3);
-            const LcaF L = lca_of_dot(sc, my_dot);
-            const float dsc = L.d * inv_t;
-            const float q0 = grp_bcast<0>(dsc), q1 = grp_bcast<1>(dsc), q2 = grp_bcast<2>(dsc);
-            const float mx = fmaxf(q0, fmaxf(q1, q2));
-            const float ex = __expf(dsc - mx);
-            const float e0 = grp_bcast<0>(ex), e1 = grp_bcast<1>(ex), e2 = grp_bcast<2>(ex);
-            const float w0 = 0.5f * (1.f + d1), w1 = 0.5f * (1.f + d2), w2 = 0.5f * (1.f + d3);
-            const float den = e0 + e1 + e2;
-            const float wbar = (e0 * w0 + e1 * w1 + e2 * w2) / den;
-            if (live && s == 0) acc_loss += (double)((w0 + w1 + w2) - wbar);
-            if (GRAD) {
-                const float my_w = s == 0 ? w0 : (s == 1 ? w1 : w2);
-                const float sm = ex / den;
-                const float gd = -(sm * (my_w - wbar)) * inv_t;
-                const float gw = (1.f - sm) + gd * L.dd_dw;                      // unscaled: upstream/kept applied later
-                if (live && s < 3 && s_live) acc_gs += (double)(gd * L.dd_ds);
-                const float c0 = 0.5f * grp_bcast<0>(gw), c1 = 0.5f * grp_bcast<1>(gw), c2 = 0.5f * grp_bcast<2>(gw);
-                if (live) {
+        }
+        // ---- phase B: every lane does the scalar part of ITS triplet (three LCA distances, the softmax, the weights)
+        bool live = lv_own;
+        if (kind >= 0) live = live && keep_rule(0.5f * (1.f + D1) - 0.5f * (1.f + D2), margin, kind);
+        if (live) ++kept;
+        const LcaF L1 = lca_of_dot(sc, D1), L2 = lca_of_dot(sc, D2), L3 = lca_of_dot(sc, D3);
+        const float q0 = L1.d * inv_t, q1 = L2.d * inv_t, q2 = L3.d * inv_t;
+        const float mx = fmaxf(q0, fmaxf(q1, q2));
+        const float e0 = __expf(q0 - mx), e1 = __expf(q1 - mx), e2 = __expf(q2 - mx);
+        const float w0 = 0.5f * (1.f + D1), w1 = 0.5f * (1.f + D2), w2 = 0.5f * (1.f + D3);
+        const float den = e0 + e1 + e2;
+        const float wbar = (e0 * w0 + e1 * w1 + e2 * w2) / den;
+        if (live) acc_loss += (double)((w0 + w1 + w2) - wbar);
+        if (GRAD) {
+            const float sm0 = e0 / den, sm1 = e1 / den, sm2 = e2 / den;
+            const float gd0 = -(sm0 * (w0 - wbar)) * inv_t, gd1 = -(sm1 * (w1 - wbar)) * inv_t,
+                        gd2 = -(sm2 * (w2 - wbar)) * inv_t;
+            // unscaled weights of the three similarity gradients: upstream/kept are applied later
+            const float c0_own = 0.5f * ((1.f - sm0) + gd0 * L1.dd_dw), c1_own = 0.5f * ((1.f - sm1) + gd1 * L2.dd_dw),
+                        c2_own = 0.5f * ((1.f - sm2) + gd2 * L3.dd_dw);
+            if (live && s_live)
+                acc_gs += (double)(gd0 * L1.dd_ds) + (double)(gd1 * L2.dd_ds) + (double)(gd2 * L3.dd_ds);
+
+            // ---- phase C: the group walks the 8 triplets again for the row gradients (rows re-read through L2)
+            int ia_sh = ia_own, ip_sh = ip_own, in_sh = in_own;
+            int cp_sh = live ? cpos_own : -2;                            // -2: dropped triplet, -1: positive not tabled
+            int c0_sh = __float_as_int(c0_own), c1_sh = __float_as_int(c1_own), c2_sh = __float_as_int(c2_own);
+            int ia = grp_bcast<0>(ia_sh), ip = grp_bcast<0>(ip_sh), in = grp_bcast<0>(in_sh);
+            IO::load(xn, E, ia, s, av);
+            IO::load(xn, E, ip, s, pv);
+            IO::load(xn, E, in, s, nv);
+#pragma unroll 1
+            for (int j8 = 0; j8 < SUB; ++j8) {
+                int ia2 = 0, ip2 = 0, in2 = 0;
+                if (j8 + 1 < SUB) {
+                    ia2 = grp_bcast<1>(ia_sh);
+                    ip2 = grp_bcast<1>(ip_sh);
+                    in2 = grp_bcast<1>(in_sh);
+                    IO::load(xn, E, ia2, s, av2);
+                    IO::load(xn, E, ip2, s, pv2);
+                    IO::load(xn, E, in2, s, nv2);
+                }
+                const int cpos = grp_bcast<0>(cp_sh);
+                const bool lv = cpos > -2;
+                const float c0 = __int_as_float(grp_bcast<0>(c0_sh)), c1 = __int_as_float(grp_bcast<0>(c1_sh)),
+                            c2 = __int_as_float(grp_bcast<0>(c2_sh));
+                if (lv) {
                     if (ia != cur) {
                         if (cur >= 0) {
 #pragma unroll
@@ -684,7 +714,7 @@ __global__ __launch_bounds__(SB_THREADS) void hyphc_sampled_kernel(
                     // positive row: LDS table of the workgroup's class, else straight to memory
                     if (cpos >= 0) {
 #pragma unroll
-                        for (int j = 0; j < EPL; ++j) atomicAdd(cache + cpos * E + s * EPL + j, c0 * av[j] + c2 * nv[j]);
+                        for (int j = 0; j < EPL; ++j) atomicAdd(cache + cpos * TS + j * SUB + s, c0 * av[j] + c2 * nv[j]);
                     } else {
 #pragma unroll
                         for (int j = 0; j < EPL; ++j) atomicAdd(gxn + (unsigned)(ip * E + s * EPL + j), c0 * av[j] + c2 * nv[j]);
@@ -694,10 +724,10 @@ __global__ __launch_bounds__(SB_THREADS) void hyphc_sampled_kernel(
                 float* slab = stage + (threadIdx.x >> 6) * (8 * LD);
                 const int gi = lane >> 3;
 #pragma unroll
-                for (int j = 0; j < EPL; ++j) slab[gi * LD + s * EPL + j] = live ? c1 * av[j] + c2 * pv[j] : 0.f;
+                for (int j = 0; j < EPL; ++j) slab[gi * LD + s * EPL + j] = lv ? c1 * av[j] + c2 * pv[j] : 0.f;
                 __builtin_amdgcn_s_waitcnt(0xC07F);
                 constexpr int RPI = 64 / E;
-                const int in_live = live ? in : -1;                  // uniform inside a group: read through v_readlane
+                const int in_live = lv ? in : -1;                    // uniform inside a group: read through v_readlane
 #pragma unroll
                 for (int r = 0; r < EPL; ++r) {
                     const int tw = r * RPI + lane / E, e = lane % E;
@@ -709,12 +739,13 @@ __global__ __launch_bounds__(SB_THREADS) void hyphc_sampled_kernel(
                     }
                     if (rn >= 0) atomicAdd(gxn + (unsigned)(rn * E + e), slab[tw * LD + e]);
                 }
-            }
-            ia = ia2; ip = ip2; in = in2;
-            ia_sh = grp_shift_down(ia_sh); ip_sh = grp_shift_down(ip_sh); in_sh = grp_shift_down(in_sh);
-            lv_sh = grp_shift_down(lv_sh); cp_sh = grp_shift_down(cp_sh);
+                ia = ia2; ip = ip2; in = in2;
+                ia_sh = grp_shift_down(ia_sh); ip_sh = grp_shift_down(ip_sh); in_sh = grp_shift_down(in_sh);
+                cp_sh = grp_shift_down(cp_sh);
+                c0_sh = grp_shift_down(c0_sh); c1_sh = grp_shift_down(c1_sh); c2_sh = grp_shift_down(c2_sh);
 #pragma unroll
-            for (int j = 0; j < EPL; ++j) { av[j] = av2[j]; pv[j] = pv2[j]; nv[j] = nv2[j]; }
+                for (int j = 0; j < EPL; ++j) { av[j] = av2[j]; pv[j] = pv2[j]; nv[j] = nv2[j]; }
+            }
         }
     }
     if (GRAD && cur >= 0) {
@@ -737,7 +768,7 @@ __global__ __launch_bounds__(SB_THREADS) void hyphc_sampled_kernel(
         for (int r0 = wave * RPW; r0 < rows; r0 += (SB_THREADS / 64) * RPW) {
             const int r = r0 + lane / E, e = lane % E;
             if (r < rows) {
-                const float v = cache[r * E + e];
+                const float v = cache[r * TS + (e % EPL) * SUB + e / EPL];
                 if (v != 0.f) atomicAdd(gxn + (int64_t)order[off_cb + r] * E + e, v);
             }
         }
@@ -1173,9 +1204,9 @@ extern "C" int hpcs_hyphc_sampled(const float* xn, const int64_t* labels, const 
     const int LD = E + 8;
     const size_t slab_bytes = (size_t)(SB_THREADS / 64) * 8 * LD * sizeof(float);
     // one 1024-thread workgroup per CU (forcing 8 waves/SIMD spills: measured 2.4x slower): 128 KB of LDS
-    int RC = grad ? (int)((128 * 1024 - slab_bytes) / (E * sizeof(float))) : 0;     // rows of the positive table
+    int RC = grad ? (int)((128 * 1024 - slab_bytes) / ((E + 8) * sizeof(float))) : 0;     // rows of the positive table
     if (RC > 1024) RC = 1024;
-    const size_t lds = (size_t)RC * E * sizeof(float) + slab_bytes;
+    const size_t lds = (size_t)RC * (E + 8) * sizeof(float) + slab_bytes;
 #define HPCS_SAMPLED_CASE(EPL)                                                                                        \
     if (E == 8 * EPL) {                                                                                               \
         if (grad) {                                                                                                   \
