@@ -729,7 +729,8 @@ __global__ void project_max_fwd_kernel(const float* __restrict__ x, const float*
     }
 }
 
-// sparse backward: thread per (b, i); gx / gz must be zero-filled by the caller (gz via atomics)
+// sparse backward: thread per (b, i); gx / gz must be zero-filled (or, for gx, hold the gradient to add to) by the
+// caller (both via atomics); a null gx, or a null gz (then gxc is skipped too), leaves that part out
 __global__ void project_max_bwd_kernel(const float* __restrict__ x, const float* __restrict__ xc, const float* __restrict__ z,
                                        const int32_t* __restrict__ arg, const float* __restrict__ gout, int B, int C, int Cc,
                                        int N, float* __restrict__ gx, float* __restrict__ gxc, float* __restrict__ gz) {
@@ -754,12 +755,15 @@ __global__ void project_max_bwd_kernel(const float* __restrict__ x, const float*
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const float zjk = zp[(int64_t)(j * 3 + k) * N + n];
-            if (i < C) atomicAdd(gx + ((int64_t)(b * C + i) * 3 + j) * N + n, g * zjk);   // the 3 k's may share n
-            else gc[j] += g * zjk;
-            atomicAdd(gz + ((int64_t)b * 9 + j * 3 + k) * N + n, g * xv[j]);
+            if (i < C) {
+                if (gx) atomicAdd(gx + ((int64_t)(b * C + i) * 3 + j) * N + n, g * zjk);   // the 3 k's may share n
+            } else {
+                gc[j] += g * zjk;
+            }
+            if (gz) atomicAdd(gz + ((int64_t)b * 9 + j * 3 + k) * N + n, g * xv[j]);
         }
     }
-    if (i >= C) {
+    if (i >= C && gz) {
         float* q = gxc + (int64_t)(b * Cc + (i - C)) * 3;
         q[0] = gc[0]; q[1] = gc[1]; q[2] = gc[2];
     }
@@ -1194,13 +1198,14 @@ extern "C" int hpcs_project_max_fwd(const float* x, const float* xconst, const f
 }
 
 extern "C" int hpcs_project_max_bwd(const float* x, const float* xconst, const float* z, const int32_t* arg,
-                                    const float* gout, int B, int C, int Cc, int N, float* gx, float* gxconst, float* gz,
-                                    hpcs_stream_t stream) {
-    if (!x || !z || !arg || !gout || !gx || !gz || (Cc > 0 && (!xconst || !gxconst))) return HPCS_ERR_NULL;
+                                    const float* gout, int B, int C, int Cc, int N, float* gx, int gx_accumulate,
+                                    float* gxconst, float* gz, hpcs_stream_t stream) {
+    if (!x || !z || !arg || !gout || (!gx && !gz) || (Cc > 0 && (!xconst || (gz && !gxconst)))) return HPCS_ERR_NULL;
     if (B < 0 || C <= 0 || Cc < 0 || N <= 0) return HPCS_ERR_SHAPE;
     if (B == 0) return HPCS_OK;
-    if (hipMemsetAsync(gx, 0, sizeof(float) * (size_t)B * C * 3 * N, ST) != hipSuccess) return HPCS_ERR_HIP;
-    if (hipMemsetAsync(gz, 0, sizeof(float) * (size_t)B * 9 * N, ST) != hipSuccess) return HPCS_ERR_HIP;
+    if (gx && !gx_accumulate && hipMemsetAsync(gx, 0, sizeof(float) * (size_t)B * C * 3 * N, ST) != hipSuccess)
+        return HPCS_ERR_HIP;
+    if (gz && hipMemsetAsync(gz, 0, sizeof(float) * (size_t)B * 9 * N, ST) != hipSuccess) return HPCS_ERR_HIP;
     hipLaunchKernelGGL(project_max_bwd_kernel, dim3(hpcs_cdiv((int64_t)B * (C + Cc), 128)), dim3(128), 0, ST, x, xconst, z, arg,
                        gout, B, C, Cc, N, gx, gxconst, gz);
     HPCS_CHECK_LAUNCH();

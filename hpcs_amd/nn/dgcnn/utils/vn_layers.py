@@ -94,12 +94,12 @@ class VNLinearLeakyReLU(nn.Module):                            # vn_layers.py:48
         self.batchnorm = VNBatchNorm(out_channels, dim=dim)
         self.map_to_dir = nn.Linear(in_channels, 1 if share_nonlinearity else out_channels, bias=False)
 
-    def forward(self, x, pool_k=0, xconst=None):
+    def forward(self, x, pool_k=0, xconst=None, hub=None):
         """pool_k>0 additionally averages over the trailing dim of size pool_k (fused mean_pool).
         xconst [B,Cc,3]: the last Cc input channels given as per-cloud constants instead of expanded over N."""
         bn = self.batchnorm.bn
         out = ops.vn_layer(_flat(x), self.map_to_feat.weight, self.map_to_dir.weight, bn.weight, bn.bias, bn.running_mean,
-                           bn.running_var, self.training, slope=self.negative_slope, pool_k=pool_k, xconst=xconst)
+                           bn.running_var, self.training, slope=self.negative_slope, pool_k=pool_k, xconst=xconst, hub=hub)
         if self.training:
             bump(bn)
         return out
@@ -150,10 +150,17 @@ class VNStdFeature(nn.Module):                                 # vn_layers.py:15
                                      negative_slope=negative_slope)
         self.vn_lin = nn.Linear(in_channels // 4, 3, bias=False)
 
-    def frame(self, x, xconst=None):
-        z = self.vn2(self.vn1(x, xconst=xconst))
+    def frame(self, x, xconst=None, hub=None):
+        """xconst: the N-constant half of vn1's input (tensor), or "mean": vn1 forms it as the mean of x over the
+        positions and the call returns (z0, mean)."""
+        h = self.vn1(x, xconst=xconst, hub=hub)            # hub: ops.GradHub for sparse gradients of x
+        xmean = None
+        if isinstance(xconst, str):
+            h, xmean = h
+        z = self.vn2(h)
         z = ops.chan_mix(z, self.vn_lin.weight, sink=(self.vn_lin.weight, ...))        # [B,3,3,N]
-        return z.transpose(1, 2).contiguous()
+        z0 = z.transpose(1, 2).contiguous()
+        return z0 if xmean is None else (z0, xmean)
 
     def forward(self, x):
         z0 = self.frame(x)

@@ -121,12 +121,13 @@ class VN_DGCNN_partseg(nn.Module):
         x123 = torch.cat((x1, x2, x3), dim=1)                                   # [B,63,3,N]
 
         g6 = self.conv6(x123)                                                   # [B,341,3,N]
-        gbar = ops.RowMeanFn.apply(g6)                                          # [B,341,3] mean over N
-        # vn1 sees cat(g6, mean expanded) (:82-83): the N-constant half enters its GEMM as a row bias
-        z0 = self.std_feature.frame(g6, xconst=gbar)                            # [B,3,3,N]
+        # vn1 sees cat(g6, mean expanded) (:82-83): the N-constant half enters its GEMM as a row bias, and the mean over N
+        # [B,341,3] is formed (and differentiated) inside that layer
+        hub = ops.GradHub()               # the project+max's sparse gradient of g6 lands in vn1's data gradient
+        z0, gbar = self.std_feature.frame(g6, xconst="mean", hub=hub)           # [B,3,3,N], [B,341,3]
         # invariant global feature: max over N of the frame projection of cat(g6, mean) (:84-87), fused -- the
         # [B,682,3,N] concatenation and its projection are never materialised, and the backward is sparse
-        glob = ops.ProjectMaxFn.apply(g6, gbar, z0)                             # [B,2046]
+        glob = ops.ProjectMaxFn.apply(g6, gbar, z0, hub)                        # [B,2046]
         loc = ops.FrameProjectFn.apply(x123, z0).view(B, -1, N)                 # [B,189,N]
 
         cat = self._head(self.conv7, l.view(B, -1, 1).float())                  # [B,64,1]

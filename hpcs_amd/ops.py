@@ -314,6 +314,32 @@ def row_linear(vec, W, sink=None):
 
 
 # ------------------------------------------------------------------------------------------------ a3
+class GradHub:
+    """Hands the SPARSE part of a tensor's gradient to the Function that produces its DENSE part.
+
+    g6 = conv6(x123) feeds vn1 (dense gradient, a GEMM) and the fused project+max (gradient only at the arg-max
+    positions).  Through autograd the sparse part costs a zero-filled [B,341,3,N] tensor plus an add over it; with a
+    hub the later node (ProjectMaxFn, consumer of vn1's frame) queues its scatter and the earlier node (VNLayerFn of
+    vn1, whose backward therefore runs AFTER it) applies it to its freshly written gx.  Only valid when `taker` is an
+    ancestor of `giver` in the graph, which VN_DGCNN_partseg guarantees by construction; a giver that runs after the
+    taker raises instead of dropping a gradient."""
+
+    def __init__(self):
+        self.pending = []
+        self.taken = False
+
+    def give(self, fn):
+        if self.taken:
+            raise RuntimeError("GradHub: the dense producer ran before the sparse one (graph order violated)")
+        self.pending.append(fn)
+
+    def take(self, gx):
+        self.taken = True
+        for fn in self.pending:
+            fn(gx)
+        self.pending.clear()
+
+
 def _gemm_inner3(W, x, B, K, L, rowbias3):
     """PD[b,:,a,:] = W @ x[b,:,a,:] + rowbias3[b,a,:]  -- walks a [B,K,3,L] tensor as 3B matrices of L columns."""
     W = _prep(W)
@@ -333,8 +359,9 @@ class VNLayerFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, Wf, Wd, gamma, beta, rmean, rvar, training, slope, pool_k, flags, xconst):
+    def forward(ctx, x, Wf, Wd, gamma, beta, rmean, rvar, training, slope, pool_k, flags, xconst, hub=None):
         ctx.wparams = (Wf, Wd)
+        ctx.hub = hub
         ctx.bnparams = (gamma, beta)
         x = _f32c(x)
         B, Cin = x.shape[0], x.shape[1]
@@ -346,6 +373,15 @@ class VNLayerFn(torch.autograd.Function):
         Cc = 0
         xcT = None
         ctx.wversions = (Wf._version, None if Wd is None else Wd._version)
+        ctx.mean_mode = isinstance(xconst, str)
+        if ctx.mean_mode:
+            # the constant channels ARE the mean of x over the positions (std_feature's vn1, vn_dgcnn_partseg.py:82-83):
+            # computed here and returned as a second output, so that in backward everything that flows into the mean
+            # re-enters gx as a row bias of the data-gradient GEMM instead of a broadcast tensor + an autograd add
+            if xconst != "mean":
+                raise ValueError("xconst must be a tensor, None or 'mean'")
+            xconst = torch.empty(B, Cin, 3, device=x.device, dtype=torch.float32)
+            call("hpcs_rowsum", x, B * Cin * 3, L, 1.0 / L, xconst)
         if xconst is not None:
             xconst = _f32c(xconst)
             Cc = xconst.shape[1]
@@ -381,10 +417,12 @@ class VNLayerFn(torch.autograd.Function):
         call("hpcs_vn_apply_fwd", PD, mean, rstd, gamma, beta, B, Cout, Cd, L, pool_k, slope, flags, out)
         ctx.save_for_backward(x, Wx, xcT, PD, mean, rstd, gamma, beta)
         ctx.cfg = (B, Cin, Cc, Cout, Cd, L, pool_k, slope, flags, bool(training))
+        if ctx.mean_mode:
+            return out, xconst
         return out
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g_mean=None):
         x, Wx, xcT, PD, mean, rstd, gamma, beta = ctx.saved_tensors
         B, Cin, Cc, Cout, Cd, L, pool_k, slope, flags, training = ctx.cfg
         g = _f32c(g)
@@ -398,17 +436,12 @@ class VNLayerFn(torch.autograd.Function):
         call("hpcs_vn_bwd_apply", PD, g, mean, rstd, gamma, beta, red, 1 if training else 0, B, Cout, Cd, L, pool_k, slope,
              flags, GPD)
         gx = gW = gWd = ggamma = gbeta = gxc = None
-        if ctx.needs_input_grad[0]:
-            gx = torch.empty(B * Cin * 3 * L, device=dev)
-            call("hpcs_gemm_tn", Wx, Wx.shape[1], GPD, 3 * L, Ctot * 3 * L, 0, gx, 3 * L, Cin * 3 * L, 0, Cin, 3 * L, Ctot, B, 1,
-                 None, 0)
-            gx = gx.view_as(x)
         ST = None
         if Cc:
             S = torch.empty(B, Ctot, 3, device=dev)
             call("hpcs_rowsum", GPD, B * Ctot * 3, L, 1.0, S)
             ST = S.permute(0, 2, 1).contiguous()                              # [(b,xyz), Ctot]
-            if ctx.needs_input_grad[11]:
+            if ctx.needs_input_grad[11] or (ctx.mean_mode and ctx.needs_input_grad[0]):
                 # gxc[(b,xyz), :] = ST [Wf_c; Wd_c]: two accumulating GEMMs (one per weight block), At = ST^T
                 Wf_, Wd_ = ctx.wparams          # the constant-channel columns are read from the live weights
                 if (Wf_._version, None if Wd_ is None else Wd_._version) != ctx.wversions:
@@ -422,6 +455,23 @@ class VNLayerFn(torch.autograd.Function):
                     call("hpcs_gemm_tn", STt[Cout:], 3 * B, Wdc.data_ptr(), ldd, 0, 0, gxcT, Cc, 0, 0, 3 * B, Cc, Cd, 1, 1,
                          None, 1)
                 gxc = gxcT.view(B, 3, Cc).permute(0, 2, 1)
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty(B * Cin * 3 * L, device=dev)
+            if ctx.mean_mode:
+                # d mean / d x = 1/L on every position: a per-(cloud, xyz, channel) row bias of the data-gradient GEMM
+                gm = gxcT.view(B, 3, Cin)
+                if g_mean is not None:
+                    gm = gm + _f32c(g_mean).permute(0, 2, 1)
+                gm = (gm * (1.0 / L)).contiguous()
+                call("hpcs_gemm_tn", Wx, Wx.shape[1], GPD, 3 * L, Ctot * 3 * L, L, gx, 3 * L, Cin * 3 * L, L, Cin, L, Ctot, B, 3,
+                     gm, 0)
+                gxc = None
+            else:
+                call("hpcs_gemm_tn", Wx, Wx.shape[1], GPD, 3 * L, Ctot * 3 * L, 0, gx, 3 * L, Cin * 3 * L, 0, Cin, 3 * L, Ctot,
+                     B, 1, None, 0)
+            gx = gx.view_as(x)
+            if ctx.hub is not None:
+                ctx.hub.take(gx)
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             def weight_grads():
                 gWcat = gemm_GXt(GPD, x, B, Ctot, Cin, 3 * L)
@@ -449,12 +499,13 @@ class VNLayerFn(torch.autograd.Function):
                 gWd = gWcat[Cout:] if Cd else None
         if flags & VN_BN:
             ggamma, gbeta = _bn_grads(ctx.bnparams, red, Cout, ctx.needs_input_grad[3], ctx.needs_input_grad[4])
-        return gx, gW, gWd, ggamma, gbeta, None, None, None, None, None, None, gxc
+        return gx, gW, gWd, ggamma, gbeta, None, None, None, None, None, None, gxc, None
 
 
-def vn_layer(x, Wf, Wd, gamma, beta, rmean, rvar, training, slope=0.2, pool_k=0, flags=VN_BN | VN_LRELU, xconst=None):
+def vn_layer(x, Wf, Wd, gamma, beta, rmean, rvar, training, slope=0.2, pool_k=0, flags=VN_BN | VN_LRELU, xconst=None,
+             hub=None):
     _need_cuda(x, Wf)
-    return VNLayerFn.apply(x, Wf, Wd, gamma, beta, rmean, rvar, training, slope, pool_k, flags, xconst)
+    return VNLayerFn.apply(x, Wf, Wd, gamma, beta, rmean, rvar, training, slope, pool_k, flags, xconst, hub)
 
 
 class VNEdgeLayerFn(torch.autograd.Function):
@@ -613,7 +664,8 @@ class ProjectMaxFn(torch.autograd.Function):
     """max over N of einsum('bijm,bjkm->bikm', cat(x, xconst expanded over N), z) -> [B, (C+Cc)*3], fused."""
 
     @staticmethod
-    def forward(ctx, x, xconst, z):
+    def forward(ctx, x, xconst, z, hub=None):
+        ctx.hub = hub
         x, z = _f32c(x), _f32c(z)
         B, C, _, N = x.shape
         Cc = 0 if xconst is None else xconst.shape[1]
@@ -629,11 +681,17 @@ class ProjectMaxFn(torch.autograd.Function):
         x, xc, z, arg = ctx.saved_tensors
         B, C, _, N = x.shape
         Cc = 0 if xc is None else xc.shape[1]
-        gx = torch.empty_like(x)
+        g = _f32c(g)
         gz = torch.empty_like(z)
         gxc = None if xc is None else torch.empty_like(xc)
-        call("hpcs_project_max_bwd", x, xc, z, arg, _f32c(g), B, C, Cc, N, gx, gxc, gz)
-        return gx, gxc, gz
+        if ctx.hub is not None and ctx.needs_input_grad[0]:
+            # x part: queued for the producer of x's dense gradient (GradHub); z / xconst parts now
+            call("hpcs_project_max_bwd", x, xc, z, arg, g, B, C, Cc, N, None, 0, gxc, gz)
+            ctx.hub.give(lambda gx: call("hpcs_project_max_bwd", x, xc, z, arg, g, B, C, Cc, N, gx, 1, None, None))
+            return None, gxc, gz, None
+        gx = torch.empty_like(x)
+        call("hpcs_project_max_bwd", x, xc, z, arg, g, B, C, Cc, N, gx, 0, gxc, gz)
+        return gx, gxc, gz, None
 
 
 class RowMaxFn(torch.autograd.Function):

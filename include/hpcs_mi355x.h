@@ -150,11 +150,14 @@ int hpcs_frame_project_bwd(const float* x, const float* z, const float* gout, in
                            float* gz, hpcs_stream_t stream);
 /* project_max: fused frame_project + max over N for cat(x [B,C,3,N], xconst [B,Cc,3] expanded) (vn_dgcnn_partseg.py
  * :82-87): out/arg [B, C+Cc, 3]; the projected [B,C+Cc,3,N] tensor is never written.  bwd is sparse (argmax only):
- * gx [B,C,3,N] and gz [B,3,3,N] are overwritten (zero-filled, then atomics), gxconst [B,Cc,3] overwritten. */
+ * gx [B,C,3,N] and gz [B,3,3,N] are overwritten (zero-filled, then atomics), gxconst [B,Cc,3] overwritten.
+ * gx == NULL skips the x part; gz == NULL skips the z and xconst parts; gx_accumulate != 0 adds the sparse x terms
+ * to the gradient already in gx instead of zero-filling it (so another producer's dense gradient can be the target). */
 int hpcs_project_max_fwd(const float* x, const float* xconst, const float* z, int B, int C, int Cc, int N, float* out,
                          int32_t* arg, hpcs_stream_t stream);
 int hpcs_project_max_bwd(const float* x, const float* xconst, const float* z, const int32_t* arg, const float* gout,
-                         int B, int C, int Cc, int N, float* gx, float* gxconst, float* gz, hpcs_stream_t stream);
+                         int B, int C, int Cc, int N, float* gx, int gx_accumulate, float* gxconst, float* gz,
+                         hpcs_stream_t stream);
 int hpcs_rowmax_fwd(const float* x, int64_t rows, int64_t L, float* out, int32_t* arg, hpcs_stream_t stream);
 int hpcs_rowmax_bwd(const float* gout, const int32_t* arg, int64_t rows, int64_t L, float* gx,
                     hpcs_stream_t stream);

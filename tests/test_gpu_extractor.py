@@ -360,3 +360,34 @@ def test_project_max_equals_unfused():
         res.append((y.detach(), xg.grad, zg.grad))
     for a, b in zip(*res):
         relclose(a, b, 1e-5)
+
+
+def test_grad_hub_and_mean_mode_equal_plain_autograd():
+    """std_feature.frame(x, 'mean', hub) + ProjectMaxFn(..., hub): the mean formed inside vn1 and the project+max's sparse
+    x-gradient applied by vn1's backward give the same gradients as RowMeanFn + plain autograd accumulation."""
+    from hpcs_amd import ops
+    from hpcs_amd.nn.dgcnn.utils.vn_layers import VNStdFeature
+    B, C, N = 2, 8, 160
+    torch.manual_seed(11)
+    feat = VNStdFeature(2 * C, dim=4, normalize_frame=False).to(dev).train()
+    x = det_normalish((B, C, 3, N), 910)
+    w = None
+    res = []
+    for mode in ("hub", "plain"):
+        feat.zero_grad(set_to_none=True)
+        xg = x.to(dev).requires_grad_(True)
+        if mode == "hub":
+            hub = ops.GradHub()
+            z0, xbar = feat.frame(xg, xconst="mean", hub=hub)
+            y = ops.ProjectMaxFn.apply(xg, xbar, z0, hub)
+        else:
+            xbar = ops.RowMeanFn.apply(xg)
+            z0 = feat.frame(xg, xconst=xbar)
+            y = ops.ProjectMaxFn.apply(xg, xbar, z0)
+        if w is None:
+            w = det_uniform(tuple(y.shape), 911).to(dev)
+        (y * w).sum().backward()
+        res.append([y.detach(), xg.grad] + [p.grad.clone() for p in feat.parameters() if p.grad is not None])
+    assert len(res[0]) == len(res[1]) and len(res[0]) > 4
+    for a, b in zip(*res):
+        relclose(a, b, 2e-5)
