@@ -27,6 +27,21 @@ def random_rotations(B, device, generator=None):
     return R.view(B, 3, 3)
 
 
+def rotate_to_channels_first(points, rot=None, seed=0, return_rot=False):
+    """points [B,N,3] -> [B,3,N] = transpose(points @ R) with one Haar rotation per cloud, in ONE launch
+    (shapenet_hyp_hc.py:63-73).  rot [B,3,3] given: use it; else quaternions from the counter RNG keyed by `seed`."""
+    from . import _lib
+    if not points.is_cuda:
+        raise _lib.HpcsNativeError("hpcs_amd needs HIP-device tensors (no CPU fallback)")
+    pts = points.contiguous() if points.dtype == torch.float32 else points.float().contiguous()
+    B, N, _ = pts.shape
+    x = torch.empty(B, 3, N, device=pts.device, dtype=torch.float32)
+    R = torch.empty(B, 3, 3, device=pts.device, dtype=torch.float32) if return_rot else None
+    rin = None if rot is None else rot.to(torch.float32).contiguous()
+    _lib.call("hpcs_so3_rotate_points", pts, B, N, int(seed) & (2 ** 63 - 1), rin, x, R)
+    return (x, R) if return_rot else x
+
+
 def to_categorical(y, num_classes):
     """1-hot encode (hpcs/utils/data.py:24-29), on the device of y."""
     return torch.nn.functional.one_hot(y.long(), num_classes).float()
@@ -51,6 +66,8 @@ class HypHCStep(torch.nn.Module):
         else:
             self.metric_hyp_loss = MetricHyperbolicLoss(cosface=cosface, **common)
         self.lr = lr
+        self._rot_seed = int(torch.initial_seed()) & (2 ** 62 - 1)
+        self._rot_calls = 0
         self.side_stream_wgrad = True
         self.optimizer = None
         self.bucket = None
@@ -64,11 +81,11 @@ class HypHCStep(torch.nn.Module):
 
     def forward_losses(self, points, label, targets, plan=None, rot=None, drop_masks=None):
         """points [B,N,3], label [B] category ids, targets [B,N] part ids (all on the device)."""
-        B = points.shape[0]
         if self.train_rotation == "so3":
-            R = random_rotations(B, points.device) if rot is None else rot
-            points = torch.matmul(points, R)              # transform_points: row vectors times R
-        x = points.transpose(2, 1).contiguous().float()
+            self._rot_calls += 1            # counter RNG stream: (torch seed at configure time, call index)
+            x = rotate_to_channels_first(points, rot=rot, seed=self._rot_seed + self._rot_calls)
+        else:
+            x = points.transpose(2, 1).contiguous().float()
         decode = to_categorical(label, self.num_categories)
         x_euclidean = self.nn_feat(x, decode) if drop_masks is None else self.nn_feat(x, decode, drop_masks=drop_masks)
         x_poincare = self.nn_emb(x_euclidean) if self.nn_emb is not None else x_euclidean

@@ -279,6 +279,13 @@ typedef struct {
 int hpcs_radam_step(const hpcs_radam_desc* desc_dev, int n_tensors, int64_t total_rows_hint, int lanes_per_row,
                     float beta1, float beta2, float eps, float weight_decay, hpcs_stream_t stream);
 
+/* ---- caller-side augmentation at the head of the step: hpcs/models/shapenet_hyp_hc.py:63-73 ------------------
+ * One rotation per cloud (pytorch3d random_rotations: normalised Gaussian quaternion; drawn from a counter RNG keyed
+ * by `seed`, or taken from rot_in [B,3,3] when given), points [B,N,3] -> x_out [B,3,N] = transpose(points @ R);
+ * rot_out [B,3,3] (optional) receives the matrices used. */
+int hpcs_so3_rotate_points(const float* points, int B, int N, uint64_t seed, const float* rot_in, float* x_out,
+                           float* rot_out, hpcs_stream_t stream);
+
 /* flat fp32 helpers used by the data-parallel wrapper (gradient bucket pack/unpack+scale) */
 int hpcs_scale_inplace(float* x, int64_t n, float s, hpcs_stream_t stream);
 

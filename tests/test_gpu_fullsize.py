@@ -135,3 +135,23 @@ def test_side_stream_weight_grads_match_inline():
     noise = float((flats[1] - flats[2]).norm() / flats[1].norm())
     assert noise < 1e-4
     assert float((flats[0] - flats[1]).norm() / flats[0].norm()) < max(1e-5, 4 * noise)
+
+
+def test_so3_rotate_kernel_matches_torch_and_is_haar_like():
+    from hpcs_amd.step import rotate_to_channels_first, random_rotations
+    B, N = 64, 300
+    pts = det_cloud(B, N, 520).transpose(1, 2).contiguous().to(dev)          # [B,N,3]
+    R = random_rotations(B, dev)
+    x = rotate_to_channels_first(pts, rot=R)
+    want = torch.matmul(pts, R).transpose(1, 2)
+    assert torch.allclose(x, want, atol=1e-6)
+    x2, R2 = rotate_to_channels_first(pts, seed=7, return_rot=True)
+    eye = torch.eye(3, device=dev)
+    assert float((R2 @ R2.transpose(1, 2) - eye).abs().max()) < 1e-5            # orthonormal
+    assert float((torch.linalg.det(R2) - 1).abs().max()) < 1e-5                # proper rotations
+    assert torch.allclose(x2, torch.matmul(pts, R2).transpose(1, 2), atol=1e-6)
+    x3, R3 = rotate_to_channels_first(pts, seed=8, return_rot=True)
+    assert float((R2 - R3).abs().max()) > 0.1                                   # a new seed gives new rotations
+    Rm = rotate_to_channels_first(torch.zeros(4096, 1, 3, device=dev), seed=3, return_rot=True)[1]
+    assert float(Rm.mean(0).abs().max()) < 0.05                                 # Haar: E[R] = 0
+    assert abs(float(torch.diagonal(Rm, dim1=1, dim2=2).sum(1).var()) - 1.0) < 0.1    # Var(trace R) = 1 on SO(3)
