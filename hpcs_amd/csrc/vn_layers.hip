@@ -902,8 +902,8 @@ extern "C" int hpcs_edge_gather_bwd(const float* gout, const int64_t* idx, int B
     return HPCS_OK;
 }
 
-static int vn_norm_stats_impl(PdRef pd, int B, int Cout, double* sums, hipStream_t st) {
-    if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * Cout, st) != hipSuccess) return HPCS_ERR_HIP;
+static int vn_norm_stats_impl(PdRef pd, int B, int Cout, double* sums, int zeroed, hipStream_t st) {
+    if (!zeroed && hipMemsetAsync(sums, 0, sizeof(double) * 2 * Cout, st) != hipSuccess) return HPCS_ERR_HIP;
     if (B == 0) return HPCS_OK;
     hipLaunchKernelGGL(vn_norm_stats_kernel, dim3(hpcs_cdiv((int64_t)B * pd.L, TPB * ITEMS), Cout), dim3(TPB), 0, st, pd, B,
                        pd.Ctot, pd.L, Cout, sums);
@@ -911,17 +911,17 @@ static int vn_norm_stats_impl(PdRef pd, int B, int Cout, double* sums, hipStream
     return HPCS_OK;
 }
 
-extern "C" int hpcs_vn_norm_stats(const float* PD, int B, int Cout, int Ctot, int64_t L, double* sums, hpcs_stream_t stream) {
+extern "C" int hpcs_vn_norm_stats(const float* PD, int B, int Cout, int Ctot, int64_t L, double* sums, int sums_zeroed, hpcs_stream_t stream) {
     if (!PD || !sums) return HPCS_ERR_NULL;
     if (bad_dims(B, Cout, L) || Ctot < Cout || Cout > 65535) return HPCS_ERR_SHAPE;
-    return vn_norm_stats_impl(PdRef{PD, nullptr, Ctot, L, 0, 0}, B, Cout, sums, ST);
+    return vn_norm_stats_impl(PdRef{PD, nullptr, Ctot, L, 0, 0}, B, Cout, sums, sums_zeroed, ST);
 }
 
 extern "C" int hpcs_vn_edge_norm_stats(const float* UV, const int64_t* idx, int B, int Cout, int Ctot, int N, int k,
-                                       double* sums, hpcs_stream_t stream) {
+                                       double* sums, int sums_zeroed, hpcs_stream_t stream) {
     if (!UV || !idx || !sums) return HPCS_ERR_NULL;
     if (B < 0 || Cout <= 0 || N <= 0 || k <= 0 || Ctot < Cout || Cout > 65535) return HPCS_ERR_SHAPE;
-    return vn_norm_stats_impl(PdRef{UV, idx, Ctot, (int64_t)N * k, N, k}, B, Cout, sums, ST);
+    return vn_norm_stats_impl(PdRef{UV, idx, Ctot, (int64_t)N * k, N, k}, B, Cout, sums, sums_zeroed, ST);
 }
 
 extern "C" int hpcs_bn_finalize(const double* sums, int C, int64_t count, float eps, float momentum, float* running_mean,
@@ -966,9 +966,9 @@ static int vn_apply_fwd_impl(PdRef pd, const float* mean, const float* rstd, con
 
 static int vn_bwd_reduce_impl(PdRef pd, const float* gout, const float* mean, const float* rstd, const float* gamma,
                               const float* beta, int B, int Cout, int Cd, int pool_k, float slope, int flags, double* red,
-                              hipStream_t st) {
+                              int zeroed, hipStream_t st) {
     if (!(flags & HPCS_VN_BN)) return HPCS_ERR_UNSUPPORTED;
-    if (hipMemsetAsync(red, 0, sizeof(double) * 2 * Cout, st) != hipSuccess) return HPCS_ERR_HIP;
+    if (!zeroed && hipMemsetAsync(red, 0, sizeof(double) * 2 * Cout, st) != hipSuccess) return HPCS_ERR_HIP;
     if (B == 0) return HPCS_OK;
     hipLaunchKernelGGL(vn_bwd_reduce_kernel, dim3(hpcs_cdiv((int64_t)B * pd.L, TPB * ITEMS), Cout), dim3(TPB), 0, st, pd, gout,
                        mean, rstd, gamma, beta, B, Cout, Cd, pd.L, pool_k, slope, flags, red);
@@ -1004,12 +1004,12 @@ extern "C" int hpcs_vn_apply_fwd(const float* PD, const float* mean, const float
 
 extern "C" int hpcs_vn_bwd_reduce(const float* PD, const float* gout, const float* mean, const float* rstd,
                                   const float* gamma, const float* beta, int B, int Cout, int Cd, int64_t L, int pool_k,
-                                  float slope, int flags, double* red, hpcs_stream_t stream) {
+                                  float slope, int flags, double* red, int red_zeroed, hpcs_stream_t stream) {
     int rc = vn_args_ok(PD, mean, rstd, gamma, beta, B, Cout, Cd, L, pool_k, flags);
     if (rc) return rc;
     if (!gout || !red) return HPCS_ERR_NULL;
     return vn_bwd_reduce_impl(PdRef{PD, nullptr, Cout + Cd, L, 0, 0}, gout, mean, rstd, gamma, beta, B, Cout, Cd, pool_k,
-                              slope, flags, red, ST);
+                              slope, flags, red, red_zeroed, ST);
 }
 
 extern "C" int hpcs_vn_bwd_apply(const float* PD, const float* gout, const float* mean, const float* rstd,
@@ -1045,14 +1045,14 @@ extern "C" int hpcs_vn_edge_apply_fwd(const float* UV, const int64_t* idx, const
 
 extern "C" int hpcs_vn_edge_bwd_reduce(const float* UV, const int64_t* idx, const float* gout, const float* mean,
                                        const float* rstd, const float* gamma, const float* beta, int B, int Cout, int Cd,
-                                       int N, int k, int pool, float slope, int flags, double* red, hpcs_stream_t stream) {
+                                       int N, int k, int pool, float slope, int flags, double* red, int red_zeroed, hpcs_stream_t stream) {
     int rc = edge_args_ok(UV, idx, B, N, k);
     if (rc) return rc;
     rc = vn_args_ok(UV, mean, rstd, gamma, beta, B, Cout, Cd, (int64_t)N * k, pool ? k : 0, flags);
     if (rc) return rc;
     if (!gout || !red) return HPCS_ERR_NULL;
     return vn_bwd_reduce_impl(PdRef{UV, idx, Cout + Cd, (int64_t)N * k, N, k}, gout, mean, rstd, gamma, beta, B, Cout, Cd,
-                              pool ? k : 0, slope, flags, red, ST);
+                              pool ? k : 0, slope, flags, red, red_zeroed, ST);
 }
 
 extern "C" int hpcs_vn_edge_bwd_apply(const float* UV, const int64_t* idx, const float* gout, const float* mean,
@@ -1102,10 +1102,10 @@ extern "C" int hpcs_edge_grad_reduce(const float* GPD, const int64_t* idx, int B
     return HPCS_OK;
 }
 
-extern "C" int hpcs_bn_stats(const float* Y, int B, int C, int64_t L, double* sums, hpcs_stream_t stream) {
+extern "C" int hpcs_bn_stats(const float* Y, int B, int C, int64_t L, double* sums, int sums_zeroed, hpcs_stream_t stream) {
     if (!Y || !sums) return HPCS_ERR_NULL;
     if (bad_dims(B, C, L) || C > 65535) return HPCS_ERR_SHAPE;
-    if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, ST) != hipSuccess) return HPCS_ERR_HIP;
+    if (!sums_zeroed && hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, ST) != hipSuccess) return HPCS_ERR_HIP;
     if (B == 0) return HPCS_OK;
     hipLaunchKernelGGL(bn_stats_kernel, dim3(hpcs_cdiv((int64_t)B * L, TPB * ITEMS), C), dim3(TPB), 0, ST, Y, B, C, L, sums);
     HPCS_CHECK_LAUNCH();
@@ -1126,10 +1126,10 @@ extern "C" int hpcs_bn_act_fwd(const float* Y, const float* mean, const float* r
 
 extern "C" int hpcs_bn_act_bwd_reduce(const float* Y, const float* gout, const float* mean, const float* rstd,
                                       const float* gamma, const float* beta, const float* mask, int B, int C, int64_t L,
-                                      float slope, double* red, hpcs_stream_t stream) {
+                                      float slope, double* red, int red_zeroed, hpcs_stream_t stream) {
     if (!Y || !gout || !mean || !rstd || !gamma || !beta || !red) return HPCS_ERR_NULL;
     if (bad_dims(B, C, L) || C > 65535) return HPCS_ERR_SHAPE;
-    if (hipMemsetAsync(red, 0, sizeof(double) * 2 * C, ST) != hipSuccess) return HPCS_ERR_HIP;
+    if (!red_zeroed && hipMemsetAsync(red, 0, sizeof(double) * 2 * C, ST) != hipSuccess) return HPCS_ERR_HIP;
     if (B == 0) return HPCS_OK;
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(hpcs_cdiv((int64_t)B * L, TPB * ITEMS), C), dim3(TPB), 0, ST, Y, gout,
                        mean, rstd, gamma, beta, mask, B, C, L, slope, red);

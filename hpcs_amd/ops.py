@@ -28,6 +28,36 @@ def _f32c_keep(W):
     return W if W.stride(-1) == 1 else W.contiguous()
 
 
+class _ZeroArena:
+    """fp64 accumulators (BatchNorm statistics and their backward reductions: ~26 per step) are slices of ONE buffer that
+    the step driver clears with a single memset (`zero_arena_reset`), instead of one memset node per accumulator.
+    Without a reset in the current step, or once the arena is used up, each accumulator is a fresh torch.zeros."""
+    buf = None
+    off = 0
+    SIZE = 1 << 16
+
+
+def zero_arena_reset(device):
+    a = _ZeroArena
+    if a.buf is None or a.buf.device != torch.device(device):
+        a.buf = torch.empty(a.SIZE, dtype=torch.float64, device=device)
+    a.buf.zero_()
+    a.off = 0
+
+
+def zero_arena_release():
+    _ZeroArena.off = _ZeroArena.SIZE          # nothing more is handed out until the next reset
+
+
+def _zeros64(n, device):
+    a = _ZeroArena
+    if a.buf is not None and a.off + n <= a.SIZE and a.buf.device == device:
+        v = a.buf[a.off:a.off + n]
+        a.off += n
+        return v
+    return torch.zeros(n, dtype=torch.float64, device=device)
+
+
 def _pad4(n):
     return (n + 3) // 4 * 4
 
@@ -407,8 +437,8 @@ class VNLayerFn(torch.autograd.Function):
             rstd = torch.empty(Cout, device=dev)
             sums = None
             if training:
-                sums = torch.empty(2 * Cout, device=dev, dtype=torch.float64)
-                call("hpcs_vn_norm_stats", PD, B, Cout, Ctot, L, sums)
+                sums = _zeros64(2 * Cout, dev)
+                call("hpcs_vn_norm_stats", PD, B, Cout, Ctot, L, sums, 1)
             call("hpcs_bn_finalize", sums, Cout, B * L, BN_EPS, BN_MOMENTUM, rmean, rvar, mean, rstd, 1 if training else 0)
         if pool_k:
             out = torch.empty(B, Cout, 3, L // pool_k, device=dev)
@@ -430,8 +460,8 @@ class VNLayerFn(torch.autograd.Function):
         Ctot = Cout + Cd
         red = None
         if flags & VN_BN:
-            red = torch.empty(2 * Cout, device=dev, dtype=torch.float64)
-            call("hpcs_vn_bwd_reduce", PD, g, mean, rstd, gamma, beta, B, Cout, Cd, L, pool_k, slope, flags, red)
+            red = _zeros64(2 * Cout, dev)
+            call("hpcs_vn_bwd_reduce", PD, g, mean, rstd, gamma, beta, B, Cout, Cd, L, pool_k, slope, flags, red, 1)
         GPD = torch.empty(B * Ctot * 3 * L, device=dev)
         call("hpcs_vn_bwd_apply", PD, g, mean, rstd, gamma, beta, red, 1 if training else 0, B, Cout, Cd, L, pool_k, slope,
              flags, GPD)
@@ -533,8 +563,8 @@ class VNEdgeLayerFn(torch.autograd.Function):
         rstd = torch.empty(Cout, device=dev)
         sums = None
         if training:
-            sums = torch.empty(2 * Cout, device=dev, dtype=torch.float64)
-            call("hpcs_vn_edge_norm_stats", UV, idx, B, Cout, Ctot, N, k, sums)
+            sums = _zeros64(2 * Cout, dev)
+            call("hpcs_vn_edge_norm_stats", UV, idx, B, Cout, Ctot, N, k, sums, 1)
         call("hpcs_bn_finalize", sums, Cout, B * N * k, BN_EPS, BN_MOMENTUM, rmean, rvar, mean, rstd, 1 if training else 0)
         out = torch.empty((B, Cout, 3, N) if pool else (B, Cout, 3, N, k), device=dev)
         flags = VN_BN | VN_LRELU
@@ -551,8 +581,8 @@ class VNEdgeLayerFn(torch.autograd.Function):
         g = _f32c(g)
         dev = g.device
         pl = 1 if pool else 0
-        red = torch.empty(2 * Cout, device=dev, dtype=torch.float64)
-        call("hpcs_vn_edge_bwd_reduce", UV, idx, g, mean, rstd, gamma, beta, B, Cout, Cd, N, k, pl, slope, flags, red)
+        red = _zeros64(2 * Cout, dev)
+        call("hpcs_vn_edge_bwd_reduce", UV, idx, g, mean, rstd, gamma, beta, B, Cout, Cd, N, k, pl, slope, flags, red, 1)
         GPD = torch.empty(B * Ctot * 3 * N * k, device=dev)
         call("hpcs_vn_edge_bwd_apply", UV, idx, g, mean, rstd, gamma, beta, red, 1 if training else 0, B, Cout, Cd, N, k, pl,
              slope, flags, GPD)
@@ -592,8 +622,8 @@ class BnActFn(torch.autograd.Function):
         rstd = torch.empty(C, device=dev)
         sums = None
         if training:
-            sums = torch.empty(2 * C, device=dev, dtype=torch.float64)
-            call("hpcs_bn_stats", y, B, C, L, sums)
+            sums = _zeros64(2 * C, dev)
+            call("hpcs_bn_stats", y, B, C, L, sums, 1)
         call("hpcs_bn_finalize", sums, C, B * L, BN_EPS, BN_MOMENTUM, rmean, rvar, mean, rstd, 1 if training else 0)
         out = torch.empty_like(y)
         call("hpcs_bn_act_fwd", y, mean, rstd, gamma, beta, mask, B, C, L, slope, out)
@@ -606,8 +636,8 @@ class BnActFn(torch.autograd.Function):
         y, mean, rstd, gamma, beta, mask = ctx.saved_tensors
         B, C, L, slope, training = ctx.cfg
         g = _f32c(g)
-        red = torch.empty(2 * C, device=g.device, dtype=torch.float64)
-        call("hpcs_bn_act_bwd_reduce", y, g, mean, rstd, gamma, beta, mask, B, C, L, slope, red)
+        red = _zeros64(2 * C, g.device)
+        call("hpcs_bn_act_bwd_reduce", y, g, mean, rstd, gamma, beta, mask, B, C, L, slope, red, 1)
         gy = torch.empty_like(y)
         call("hpcs_bn_act_bwd_apply", y, g, mean, rstd, gamma, beta, mask, red, 1 if training else 0, B, C, L, slope, gy)
         ggamma, gbeta = _bn_grads(ctx.bnparams, red, C, ctx.needs_input_grad[1], ctx.needs_input_grad[2])

@@ -11,7 +11,7 @@ import torch
 
 from .dp import FlatGradBucket
 from .loss.ultrametric_loss import HierarchicalMetricHyperbolicLoss, MetricHyperbolicLoss
-from .ops import deferred_weight_grads
+from .ops import deferred_weight_grads, zero_arena_release, zero_arena_reset
 from .optim import RAdam
 
 
@@ -103,6 +103,7 @@ class HypHCStep(torch.nn.Module):
         if targets_host is not None and self.metric_hyp_loss.miner:
             plan = self.metric_hyp_loss.make_plan(targets_host)
         self.bucket.zero()
+        zero_arena_reset(points.device)        # one memset for all the step's fp64 accumulators
         losses = self.forward_losses(points, label, targets, plan=plan, rot=rot, drop_masks=drop_masks)
         total = losses["loss_metric"] + losses["loss_hyp"]
         if self.side_stream_wgrad:             # dW GEMMs on a side stream, joined before the all-reduce
@@ -110,6 +111,7 @@ class HypHCStep(torch.nn.Module):
                 total.backward()
         else:
             total.backward()
+        zero_arena_release()
         self.bucket.all_reduce_mean()
         self.optimizer.step()
         losses["total_loss"] = total.detach()

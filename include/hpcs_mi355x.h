@@ -89,7 +89,9 @@ int hpcs_gemm_nt(const float* G, int ldg, int64_t strideG_o, int64_t strideG_i, 
  *   bwd_apply  : GPD [B,Cout+Cd,3,L] = (dL/dp, dL/dd) */
 #define HPCS_VN_BN 1
 #define HPCS_VN_LRELU 2
-int hpcs_vn_norm_stats(const float* PD, int B, int Cout, int Ctot, int64_t L, double* sums, hpcs_stream_t stream);
+/* Accumulators `sums` / `red` (fp64, reached with atomics): *_zeroed != 0 promises the caller already zero-filled them
+ * (e.g. slices of one arena cleared once per step), otherwise each call clears its own. */
+int hpcs_vn_norm_stats(const float* PD, int B, int Cout, int Ctot, int64_t L, double* sums, int sums_zeroed, hpcs_stream_t stream);
 int hpcs_bn_finalize(const double* sums, int C, int64_t count, float eps, float momentum, float* running_mean,
                      float* running_var, float* mean, float* rstd, int training, hpcs_stream_t stream);
 int hpcs_vn_apply_fwd(const float* PD, const float* mean, const float* rstd, const float* gamma,
@@ -97,7 +99,7 @@ int hpcs_vn_apply_fwd(const float* PD, const float* mean, const float* rstd, con
                       float* out, hpcs_stream_t stream);
 int hpcs_vn_bwd_reduce(const float* PD, const float* gout, const float* mean, const float* rstd,
                        const float* gamma, const float* beta, int B, int Cout, int Cd, int64_t L, int pool_k,
-                       float slope, int flags, double* red, hpcs_stream_t stream);
+                       float slope, int flags, double* red, int red_zeroed, hpcs_stream_t stream);
 int hpcs_vn_bwd_apply(const float* PD, const float* gout, const float* mean, const float* rstd,
                       const float* gamma, const float* beta, const double* red, int training, int B, int Cout,
                       int Cd, int64_t L, int pool_k, float slope, int flags, float* GPD, hpcs_stream_t stream);
@@ -110,13 +112,13 @@ int hpcs_vn_bwd_apply(const float* PD, const float* gout, const float* mean, con
  * materialised entry points above with L = N*k; pool != 0 fuses the mean over the k neighbours.
  * edge_grad_reduce: GPD [B,Ctot,3,N*k] -> gUV (gU = scatter-add over idx, gV = sum over k). */
 int hpcs_vn_edge_norm_stats(const float* UV, const int64_t* idx, int B, int Cout, int Ctot, int N, int k,
-                            double* sums, hpcs_stream_t stream);
+                            double* sums, int sums_zeroed, hpcs_stream_t stream);
 int hpcs_vn_edge_apply_fwd(const float* UV, const int64_t* idx, const float* mean, const float* rstd,
                            const float* gamma, const float* beta, int B, int Cout, int Cd, int N, int k, int pool,
                            float slope, int flags, float* out, hpcs_stream_t stream);
 int hpcs_vn_edge_bwd_reduce(const float* UV, const int64_t* idx, const float* gout, const float* mean,
                             const float* rstd, const float* gamma, const float* beta, int B, int Cout, int Cd, int N,
-                            int k, int pool, float slope, int flags, double* red, hpcs_stream_t stream);
+                            int k, int pool, float slope, int flags, double* red, int red_zeroed, hpcs_stream_t stream);
 int hpcs_vn_edge_bwd_apply(const float* UV, const int64_t* idx, const float* gout, const float* mean,
                            const float* rstd, const float* gamma, const float* beta, const double* red, int training,
                            int B, int Cout, int Cd, int N, int k, int pool, float slope, int flags, float* GPD,
@@ -128,12 +130,12 @@ int hpcs_edge_grad_reduce(const float* GPD, const int64_t* idx, int B, int Ctot,
 /* ---- Conv1d(k=1)+BatchNorm1d(+LeakyReLU)(+Dropout mask)  vn_dgcnn_partseg.py:40-57,97-102 ------
  * Y [B,C,L] is the Conv1d output (hpcs_gemm_tn).  slope = 1 means no activation; mask (nullable,
  * [B,C,L]) is the already scaled dropout multiplier. */
-int hpcs_bn_stats(const float* Y, int B, int C, int64_t L, double* sums, hpcs_stream_t stream);
+int hpcs_bn_stats(const float* Y, int B, int C, int64_t L, double* sums, int sums_zeroed, hpcs_stream_t stream);
 int hpcs_bn_act_fwd(const float* Y, const float* mean, const float* rstd, const float* gamma, const float* beta,
                     const float* mask, int B, int C, int64_t L, float slope, float* out, hpcs_stream_t stream);
 int hpcs_bn_act_bwd_reduce(const float* Y, const float* gout, const float* mean, const float* rstd,
                            const float* gamma, const float* beta, const float* mask, int B, int C, int64_t L,
-                           float slope, double* red, hpcs_stream_t stream);
+                           float slope, double* red, int red_zeroed, hpcs_stream_t stream);
 int hpcs_bn_act_bwd_apply(const float* Y, const float* gout, const float* mean, const float* rstd,
                           const float* gamma, const float* beta, const float* mask, const double* red,
                           int training, int B, int C, int64_t L, float slope, float* gY, hpcs_stream_t stream);
