@@ -365,6 +365,75 @@ __global__ void vn_apply_pool_fwd_kernel(PdRef pd, const float* __restrict__ mea
     op[2 * Np] = acc[2] * inv;
 }
 
+// Tiled form of the fused mean_pool for the materialised layout with pool_k % 4 == 0, pool_k <= 64: a workgroup owns 64
+// points of one (cloud, channel); thread t takes the 4 consecutive positions 4t..4t+3 of that span (six fully coalesced
+// 16-byte loads), the pool_k/4 partial sums of a point meet in LDS.  (The one-thread-per-point kernel above strides
+// its 16-byte loads by pool_k floats and ran at ~1.5 TB/s.)
+__global__ __launch_bounds__(1024) void vn_apply_pool_tile_kernel(const float* __restrict__ PD, const float* __restrict__ mean,
+                                                                  const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, int Cout, int Cd, int64_t L,
+                                                                  int pool_k, float slope, int flags, float* __restrict__ out) {
+    __shared__ float part[3][1024];
+    const int c = blockIdx.y, b = blockIdx.z;
+    const int Ctot = Cout + Cd;
+    const int cd = Cd == 1 ? Cout : Cout + c;
+    const int64_t Np = L / pool_k;
+    const int64_t n0 = (int64_t)blockIdx.x * 64;
+    const int t = threadIdx.x;
+    const int64_t l = n0 * pool_k + 4 * (int64_t)t;
+    const bool bn = flags & HPCS_VN_BN;
+    const bool act = flags & HPCS_VN_LRELU;
+    const float mu = bn ? mean[c] : 0.f, rs = bn ? rstd[c] : 1.f, ga = bn ? gamma[c] : 1.f, be = bn ? beta[c] : 0.f;
+    float acc[3] = {0.f, 0.f, 0.f};
+    if (l < L) {
+        const float* pp = PD + (((int64_t)b * Ctot + c) * 3) * L + l;
+        const float* dp = PD + (((int64_t)b * Ctot + cd) * 3) * L + l;
+        float pv[3][4], dv[3][4];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float4 u = *reinterpret_cast<const float4*>(pp + a * L);
+            pv[a][0] = u.x; pv[a][1] = u.y; pv[a][2] = u.z; pv[a][3] = u.w;
+            if (act) {
+                const float4 v = *reinterpret_cast<const float4*>(dp + a * L);
+                dv[a][0] = v.x; dv[a][1] = v.y; dv[a][2] = v.z; dv[a][3] = v.w;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            VnPoint sp;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                sp.p[a] = pv[a][q];
+                sp.d[a] = act ? dv[a][q] : 0.f;
+            }
+            vn_forward_point(sp, mu, rs, ga, be, flags);
+            float o[3];
+            vn_output_point(sp, slope, flags, o);
+            acc[0] += o[0];
+            acc[1] += o[1];
+            acc[2] += o[2];
+        }
+    }
+    part[0][t] = acc[0];
+    part[1][t] = acc[1];
+    part[2][t] = acc[2];
+    __syncthreads();
+    if (t < 64 && n0 + t < Np) {
+        const int q4 = pool_k / 4;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        for (int i = 0; i < q4; ++i) {
+            s0 += part[0][t * q4 + i];
+            s1 += part[1][t * q4 + i];
+            s2 += part[2][t * q4 + i];
+        }
+        float* op = out + (((int64_t)b * Cout + c) * 3) * Np + n0 + t;
+        const float inv = 1.f / (float)pool_k;
+        op[0] = s0 * inv;
+        op[Np] = s1 * inv;
+        op[2 * Np] = s2 * inv;
+    }
+}
+
 __device__ __forceinline__ void load_gout(const float* __restrict__ gout, int64_t b, int Cout, int c, int64_t L, int64_t l,
                                           int pool_k, float (&g)[3]) {
     if (pool_k > 0) {
@@ -422,14 +491,16 @@ __global__ void vn_bwd_apply_kernel(PdRef pd, const float* __restrict__ gout,
                                     const float* __restrict__ mean, const float* __restrict__ rstd,
                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                     const double* __restrict__ red, int training, int B, int Cout, int Cd, int64_t L,
-                                    int pool_k, float slope, int flags, float* __restrict__ GPD) {
+                                    int pool_k, float slope, int flags, float* __restrict__ GPD, int c_chunk) {
     const int Ctot = Cout + Cd;
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (int64_t)B * L) return;
     const int64_t b = e / L, l = e % L;
     const double count = (double)B * (double)L;
-    const int c_begin = SHARED ? 0 : blockIdx.y;
-    const int c_end = SHARED ? Cout : blockIdx.y + 1;
+    // SHARED (one direction channel for all features): blockIdx.y owns a chunk of channels and adds its part of the
+    // direction gradient atomically into the (pre-zeroed) direction rows
+    const int c_begin = SHARED ? blockIdx.y * c_chunk : blockIdx.y;
+    const int c_end = SHARED ? min(Cout, c_begin + c_chunk) : blockIdx.y + 1;
     const bool bn = flags & HPCS_VN_BN;
     float gdsum[3] = {0.f, 0.f, 0.f};
     float dsh[3] = {0.f, 0.f, 0.f};
@@ -486,9 +557,9 @@ __global__ void vn_bwd_apply_kernel(PdRef pd, const float* __restrict__ gout,
     }
     if (SHARED) {
         float* od = GPD + ((b * Ctot + Cout) * 3) * L + l;
-        od[0] = gdsum[0];
-        od[L] = gdsum[1];
-        od[2 * L] = gdsum[2];
+        atomicAdd(od, gdsum[0]);
+        atomicAdd(od + L, gdsum[1]);
+        atomicAdd(od + 2 * L, gdsum[2]);
     }
 }
 
@@ -950,7 +1021,10 @@ static int vn_apply_fwd_impl(PdRef pd, const float* mean, const float* rstd, con
     if (pool_k > 0) {
         const bool vec = pd.idx == nullptr && (pool_k % 4 == 0) && (L % 4 == 0) && (((uintptr_t)pd.base & 15u) == 0);
         const dim3 grid(hpcs_cdiv((int64_t)B * (L / pool_k), 64), Cout);
-        if (vec)
+        if (vec && pool_k <= 64 && B <= 65535 && Cout <= 65535)
+            hipLaunchKernelGGL(vn_apply_pool_tile_kernel, dim3(hpcs_cdiv(L / pool_k, 64), Cout, B), dim3(16 * pool_k), 0, st,
+                               pd.base, mean, rstd, gamma, beta, Cout, Cd, L, pool_k, slope, flags, out);
+        else if (vec)
             hipLaunchKernelGGL((vn_apply_pool_fwd_kernel<true>), grid, dim3(64), 0, st, pd, mean, rstd, gamma, beta, B, Cout,
                                Cd, L, pool_k, slope, flags, out);
         else
@@ -981,12 +1055,20 @@ static int vn_bwd_apply_impl(PdRef pd, const float* gout, const float* mean, con
                              float slope, int flags, float* GPD, hipStream_t st) {
     if (B == 0) return HPCS_OK;
     const int64_t L = pd.L;
-    if (Cd == 1 && (flags & HPCS_VN_LRELU))
-        hipLaunchKernelGGL((vn_bwd_apply_kernel<true>), dim3(hpcs_cdiv((int64_t)B * L, TPB), 1), dim3(TPB), 0, st, pd, gout,
-                           mean, rstd, gamma, beta, red, training, B, Cout, Cd, L, pool_k, slope, flags, GPD);
-    else
+    if (Cd == 1 && (flags & HPCS_VN_LRELU)) {
+        const int Ctot = Cout + Cd;
+        const int chunks = Cout < 16 ? Cout : 16, c_chunk = hpcs_cdiv(Cout, chunks);
+        // zero the B direction blocks [3][L] (row pitch Ctot*3*L floats) that the channel chunks add into
+        if (hipMemset2DAsync(GPD + (int64_t)Cout * 3 * L, sizeof(float) * (size_t)Ctot * 3 * L, 0, sizeof(float) * 3 * (size_t)L, B,
+                             st) != hipSuccess)
+            return HPCS_ERR_HIP;
+        hipLaunchKernelGGL((vn_bwd_apply_kernel<true>), dim3(hpcs_cdiv((int64_t)B * L, TPB), hpcs_cdiv(Cout, c_chunk)), dim3(TPB),
+                           0, st, pd, gout, mean, rstd, gamma, beta, red, training, B, Cout, Cd, L, pool_k, slope, flags, GPD,
+                           c_chunk);
+    } else {
         hipLaunchKernelGGL((vn_bwd_apply_kernel<false>), dim3(hpcs_cdiv((int64_t)B * L, TPB), Cout), dim3(TPB), 0, st, pd,
-                           gout, mean, rstd, gamma, beta, red, training, B, Cout, Cd, L, pool_k, slope, flags, GPD);
+                           gout, mean, rstd, gamma, beta, red, training, B, Cout, Cd, L, pool_k, slope, flags, GPD, 1);
+    }
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;
 }
