@@ -104,6 +104,87 @@ __global__ void class_fill_kernel(const int64_t* __restrict__ labels, int M, con
     }
 }
 
+// Blocked form for C <= 512 (three short launches instead of global atomics on C counters and C workgroups that each
+// scan all M labels): (1) per-1024-label-block class histograms in LDS, (2) one workgroup turns them into the class
+// offsets and each block's first slot per class, (3) every block places its members: in-wave ranks by ballot over
+// the classes present in the wave, the 16 waves ordered through an LDS prefix.  Stable (ascending index per class).
+constexpr int CI_TPB = 1024;
+constexpr int CI_MAXC = 512;
+__global__ __launch_bounds__(CI_TPB) void class_hist_blocks_kernel(const int64_t* __restrict__ labels, int M, int C,
+                                                                    int32_t* __restrict__ blk_cnt) {
+    __shared__ int h[CI_MAXC];
+    for (int c = threadIdx.x; c < C; c += CI_TPB) h[c] = 0;
+    __syncthreads();
+    const int i = blockIdx.x * CI_TPB + threadIdx.x;
+    if (i < M) {
+        const int64_t l = labels[i];
+        if (l >= 0 && l < C) atomicAdd(&h[(int)l], 1);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += CI_TPB) blk_cnt[(int64_t)blockIdx.x * C + c] = h[c];
+}
+__global__ __launch_bounds__(CI_MAXC) void class_scan_blocks_kernel(int32_t* __restrict__ blk_cnt, int nblk, int C,
+                                                                    int32_t* __restrict__ offsets) {
+    __shared__ int tot[CI_MAXC + 1];
+    const int c = threadIdx.x;
+    if (c < C) {
+        int t = 0;
+        for (int b = 0; b < nblk; ++b) t += blk_cnt[(int64_t)b * C + c];
+        tot[c] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int q = 0; q < C; ++q) { const int t = tot[q]; tot[q] = acc; offsets[q] = acc; acc += t; }
+        offsets[C] = acc;
+    }
+    __syncthreads();
+    if (c < C) {
+        int run = tot[c];
+        for (int b = 0; b < nblk; ++b) {
+            const int t = blk_cnt[(int64_t)b * C + c];
+            blk_cnt[(int64_t)b * C + c] = run;           // becomes: first slot of class c for block b
+            run += t;
+        }
+    }
+}
+__global__ __launch_bounds__(CI_TPB) void class_fill_blocks_kernel(const int64_t* __restrict__ labels, int M, int C,
+                                                                    const int32_t* __restrict__ blk_base,
+                                                                    int32_t* __restrict__ order) {
+    extern __shared__ int wcnt[];                        // [16][C]
+    constexpr int NW = CI_TPB / 64;
+    for (int q = threadIdx.x; q < NW * C; q += CI_TPB) wcnt[q] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = blockIdx.x * CI_TPB + threadIdx.x;
+    int cls = -1;
+    if (i < M) {
+        const int64_t l = labels[i];
+        if (l >= 0 && l < C) cls = (int)l;
+    }
+    int rank = 0;
+    unsigned long long todo = __ballot(cls >= 0);
+    while (todo) {                                       // one round per distinct class present in the wave
+        const int src = __ffsll((long long)todo) - 1;
+        const int c0 = __shfl(cls, src, 64);
+        const unsigned long long m = __ballot(cls == c0);
+        if (cls == c0) rank = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == src) wcnt[w * C + c0] = __popcll(m);
+        todo &= ~m;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += CI_TPB) {      // exclusive prefix over the waves, seeded with the block's first slot
+        int run = blk_base[(int64_t)blockIdx.x * C + c];
+        for (int j = 0; j < NW; ++j) {
+            const int t = wcnt[j * C + c];
+            wcnt[j * C + c] = run;
+            run += t;
+        }
+    }
+    __syncthreads();
+    if (cls >= 0) order[wcnt[w * C + cls] + rank] = i;
+}
+
 // ---------------------------------------------------------------------------------------------- sampler
 __global__ void sample_triplets_kernel(const int32_t* __restrict__ order, const int32_t* __restrict__ offsets,
                                        const int64_t* __restrict__ cls_toff, const int32_t* __restrict__ cls_k, int C, int M,
@@ -1001,10 +1082,28 @@ inline unsigned trip_grid(int64_t T_cap) {
 
 #define ST ((hipStream_t)stream)
 
+extern "C" size_t hpcs_class_index_workspace(int M, int C) {
+    if (M < 0 || C <= 0) return 0;
+    const size_t nblk = (size_t)hpcs_cdiv(M > 0 ? M : 1, CI_TPB);
+    return sizeof(int32_t) * (C <= CI_MAXC ? nblk * (size_t)C : (size_t)C);
+}
+
 extern "C" int hpcs_class_index(const int64_t* labels, int M, int C, int32_t* order, int32_t* offsets, int32_t* counts_ws,
-                                hpcs_stream_t stream) {
+                                size_t ws_bytes, hpcs_stream_t stream) {
     if (!labels || !order || !offsets || !counts_ws) return HPCS_ERR_NULL;
     if (M < 0 || C <= 0) return HPCS_ERR_SHAPE;
+    if (ws_bytes < hpcs_class_index_workspace(M, C)) return HPCS_ERR_WORKSPACE;
+    if (C <= CI_MAXC && M > 0) {
+        const int nblk = hpcs_cdiv(M, CI_TPB);
+        hipLaunchKernelGGL(class_hist_blocks_kernel, dim3(nblk), dim3(CI_TPB), 0, ST, labels, M, C, counts_ws);
+        HPCS_CHECK_LAUNCH();
+        hipLaunchKernelGGL(class_scan_blocks_kernel, dim3(1), dim3(CI_MAXC), 0, ST, counts_ws, nblk, C, offsets);
+        HPCS_CHECK_LAUNCH();
+        hipLaunchKernelGGL(class_fill_blocks_kernel, dim3(nblk), dim3(CI_TPB), sizeof(int) * (CI_TPB / 64) * (size_t)C, ST, labels,
+                           M, C, (const int32_t*)counts_ws, order);
+        HPCS_CHECK_LAUNCH();
+        return HPCS_OK;
+    }
     if (hipMemsetAsync(counts_ws, 0, sizeof(int32_t) * C, ST) != hipSuccess) return HPCS_ERR_HIP;
     if (M > 0) {
         hipLaunchKernelGGL(hist_kernel, dim3(hpcs_cdiv(M, TPB)), dim3(TPB), 0, ST, labels, M, C, counts_ws);

@@ -63,6 +63,39 @@ __global__ void edge_gather_bwd_center_kernel(const float* __restrict__ gout, in
     }
 }
 
+// Tiled centre part for k % 4 == 0, k <= 64: a workgroup owns 64 points of one (cloud, channel); thread t takes the 4
+// consecutive edges 4t..4t+3 of that span (fully coalesced 16-byte loads of both halves), the k/4 partial sums of a point
+// meet in LDS.  (The one-thread-per-point kernel above strides its loads by k floats: ~2 TB/s.)
+__global__ __launch_bounds__(1024) void edge_gather_bwd_center_tile_kernel(const float* __restrict__ gout, int C, int N, int k,
+                                                                           float* __restrict__ gx) {
+    __shared__ float part[3][1024];
+    const int c = blockIdx.y, b = blockIdx.z;
+    const int64_t L = (int64_t)N * k;
+    const int64_t n0 = (int64_t)blockIdx.x * 64;
+    const int t = threadIdx.x;
+    const int64_t l = n0 * k + 4 * (int64_t)t;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float sacc = 0.f;
+        if (l < L) {
+            const float4 v = *reinterpret_cast<const float4*>(gout + (((int64_t)b * 2 * C + c) * 3 + a) * L + l);
+            const float4 u = *reinterpret_cast<const float4*>(gout + (((int64_t)b * 2 * C + C + c) * 3 + a) * L + l);
+            sacc = (u.x - v.x) + (u.y - v.y) + (u.z - v.z) + (u.w - v.w);
+        }
+        part[a][t] = sacc;
+    }
+    __syncthreads();
+    if (t < 64 && n0 + t < N) {
+        const int q4 = k / 4;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            float sacc = 0.f;
+            for (int i = 0; i < q4; ++i) sacc += part[a][t * q4 + i];
+            gx[(((int64_t)b * C + c) * 3 + a) * N + n0 + t] = sacc;
+        }
+    }
+}
+
 // neighbour part.  A workgroup takes 64 consecutive edges of one cloud and all C*3 difference channels: the tile is
 // read coalesced along l, transposed through LDS, and each edge's C*3 values are added with ONE wave instruction
 // to a contiguous row of the point-major scratch tmp[b][point][CP] (full-rate atomic shape: MI355X_MICROARCH
@@ -958,7 +991,9 @@ extern "C" int hpcs_edge_gather_bwd(const float* gout, const int64_t* idx, int B
     const int64_t L = (int64_t)N * k;
     const int CP = (C * 3 + 15) / 16 * 16;
     const bool vec = (k % 4 == 0) && (((uintptr_t)gout & 15u) == 0);
-    if (vec)
+    if (vec && k <= 64)
+        hipLaunchKernelGGL(edge_gather_bwd_center_tile_kernel, dim3(hpcs_cdiv(N, 64), C, B), dim3(16 * k), 0, ST, gout, C, N, k, gx);
+    else if (vec)
         hipLaunchKernelGGL((edge_gather_bwd_center_kernel<true>), dim3(hpcs_cdiv(N, 64), C, B), dim3(64), 0, ST, gout, C, N, k, gx);
     else
         hipLaunchKernelGGL((edge_gather_bwd_center_kernel<false>), dim3(hpcs_cdiv(N, 64), C, B), dim3(64), 0, ST, gout, C, N, k, gx);

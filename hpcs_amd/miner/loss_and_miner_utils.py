@@ -65,8 +65,9 @@ def class_index(labels, C):
     M = labels.numel()
     order = torch.empty(M, dtype=torch.int32, device=dev)
     offsets = torch.empty(C + 1, dtype=torch.int32, device=dev)
-    counts_ws = torch.empty(C, dtype=torch.int32, device=dev)
-    _lib.call("hpcs_class_index", labels, M, C, order, offsets, counts_ws)
+    nbytes = _lib.call("hpcs_class_index_workspace", M, C)
+    counts_ws = torch.empty(max(nbytes // 4, 1), dtype=torch.int32, device=dev)
+    _lib.call("hpcs_class_index", labels, M, C, order, offsets, counts_ws, nbytes)
     return order, offsets
 
 

@@ -206,8 +206,9 @@ int hpcs_l2_rows_fwd(const float* x, int64_t rows, int E, float* xn, float* inv_
 int hpcs_l2_rows_bwd(const float* xn, const float* inv_norm, const float* gxn, int64_t rows, int E, float* gx,
                      int accumulate, hpcs_stream_t stream);
 int hpcs_cosine_mat(const float* xn, const float* yn, int M, int Mp, int E, float* out, hpcs_stream_t stream);
+size_t hpcs_class_index_workspace(int M, int C);
 int hpcs_class_index(const int64_t* labels, int M, int C, int32_t* order, int32_t* offsets, int32_t* counts_ws,
-                     hpcs_stream_t stream);
+                     size_t ws_bytes, hpcs_stream_t stream);
 int hpcs_sample_triplets(const int32_t* order, const int32_t* offsets, const int64_t* cls_toff,
                          const int32_t* cls_k, int C, int M, int64_t T, const int64_t* draws_pos,
                          const int64_t* draws_neg, uint64_t seed, int64_t* a, int64_t* p, int64_t* n,

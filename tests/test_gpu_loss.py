@@ -274,3 +274,16 @@ def test_hyphc_sampled_in_kernel():
     with torch.no_grad():
         l3 = crit.compute_hyp(x.to(dev), lab.to(dev))
     assert abs(float(l3) - float(lh)) <= 2e-6 * abs(float(lh))
+
+
+@pytest.mark.parametrize("M,C", [(32768, 50), (1000, 7), (5000, 600), (1, 3), (3001, 512)])
+def test_class_index_is_stable_grouping(M, C):
+    """order = members grouped by class, ascending index inside a class; offsets = exclusive class counts (both the
+    blocked C<=512 kernels and the general path)."""
+    from hpcs_amd.miner.loss_and_miner_utils import class_index
+    lab = det_int((M,), 4000 + M, C)
+    order, offsets = class_index(lab.to(dev), C)
+    want_order = torch.argsort(lab, stable=True).to(torch.int32)
+    want_off = torch.cat([torch.zeros(1, dtype=torch.int64), torch.bincount(lab, minlength=C).cumsum(0)]).to(torch.int32)
+    assert torch.equal(offsets.cpu(), want_off)
+    assert torch.equal(order.cpu(), want_order)
