@@ -20,6 +20,11 @@ __device__ __forceinline__ float sub_sum(float v) {
     v += __shfl_xor(v, 1, 64);
     v += __shfl_xor(v, 2, 64);
     v += __shfl_xor(v, 4, 64);
+    if (SUBW == 64) {
+        v += __shfl_xor(v, 8, 64);
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+    }
     return v;
 }
 
@@ -131,12 +136,16 @@ extern "C" int hpcs_radam_step(const hpcs_radam_desc* desc_dev, int n_tensors, i
                                float beta1, float beta2, float eps, float weight_decay, hpcs_stream_t stream) {
     if (!desc_dev) return HPCS_ERR_NULL;
     if (n_tensors <= 0 || total_rows_hint <= 0) return HPCS_ERR_SHAPE;
-    if (lanes_per_row != 1 && lanes_per_row != SUB) return HPCS_ERR_UNSUPPORTED;
+    if (lanes_per_row != 1 && lanes_per_row != SUB && lanes_per_row != 64) return HPCS_ERR_UNSUPPORTED;
     // layout of the table (built by the host side): n_tensors descriptors, then (n_tensors+1) int64 row starts
     const int64_t* row_start = (const int64_t*)(desc_dev + n_tensors);
     if (lanes_per_row == 1) {
         const int64_t blocks = (total_rows_hint + TPB - 1) / TPB;
         hipLaunchKernelGGL(radam_kernel<1>, dim3((unsigned)blocks), dim3(TPB), 0, (hipStream_t)stream, desc_dev, row_start,
+                           n_tensors, total_rows_hint, beta1, beta2, eps, weight_decay);
+    } else if (lanes_per_row == 64) {        // wide rows (hundreds of columns): a wave per row
+        const int64_t blocks = (total_rows_hint + (TPB / 64) - 1) / (TPB / 64);
+        hipLaunchKernelGGL(radam_kernel<64>, dim3((unsigned)blocks), dim3(TPB), 0, (hipStream_t)stream, desc_dev, row_start,
                            n_tensors, total_rows_hint, beta1, beta2, eps, weight_decay);
     } else {
         const int64_t blocks = (total_rows_hint + (TPB / SUB) - 1) / (TPB / SUB);

@@ -282,6 +282,39 @@ __global__ void vn_norm_stats_kernel(PdRef pd, int B, int Ctot, int64_t L, int C
     }
 }
 
+// Vector form for the materialised layout with L % 4 == 0: a workgroup walks VEC_ITEMS * 1024 consecutive positions of one
+// (cloud, channel) row with 16-byte loads and no index arithmetic per element (the scalar kernel above pays a 64-bit
+// division per element and ran at ~2 TB/s).
+constexpr int VEC_ITEMS = 2;
+__global__ __launch_bounds__(TPB) void vn_norm_stats_vec_kernel(const float* __restrict__ PD, int Ctot, int64_t L, int Cout,
+                                                               double* __restrict__ sums) {
+    __shared__ double red[16];
+    const int c = blockIdx.y, b = blockIdx.z;
+    const float* base = PD + (((int64_t)b * Ctot + c) * 3) * L;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < VEC_ITEMS; ++it) {
+        const int64_t l = ((int64_t)blockIdx.x * VEC_ITEMS + it) * (TPB * 4) + threadIdx.x * 4;
+        if (l < L) {
+            const float4 x = *reinterpret_cast<const float4*>(base + l);
+            const float4 y = *reinterpret_cast<const float4*>(base + L + l);
+            const float4 z = *reinterpret_cast<const float4*>(base + 2 * L + l);
+            const float n0 = sqrtf(x.x * x.x + y.x * y.x + z.x * z.x) + VN_EPS;
+            const float n1 = sqrtf(x.y * x.y + y.y * y.y + z.y * z.y) + VN_EPS;
+            const float n2 = sqrtf(x.z * x.z + y.z * y.z + z.z * z.z) + VN_EPS;
+            const float n3 = sqrtf(x.w * x.w + y.w * y.w + z.w * z.w) + VN_EPS;
+            s1 += (n0 + n1) + (n2 + n3);
+            s2 += (n0 * n0 + n1 * n1) + (n2 * n2 + n3 * n3);
+        }
+    }
+    const double r1 = hpcs_block_sum<double>((double)s1, red);
+    const double r2 = hpcs_block_sum<double>((double)s2, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(sums + c, r1);
+        atomicAdd(sums + Cout + c, r2);
+    }
+}
+
 __global__ void bn_finalize_kernel(const double* __restrict__ sums, int C, double count, float eps, float momentum,
                                    float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ mean,
                                    float* __restrict__ rstd, int training) {
@@ -509,6 +542,79 @@ __global__ void vn_bwd_reduce_kernel(PdRef pd, const float* __restrict__ gout,
             const float gnb = (gq[0] * s.p[0] + gq[1] * s.p[1] + gq[2] * s.p[2]) / s.n;
             s1 += gnb;
             s2 += gnb * s.xhat;
+        }
+    }
+    const double r1 = hpcs_block_sum<double>((double)s1, red);
+    const double r2 = hpcs_block_sum<double>((double)s2, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(red_out + c, r1);
+        atomicAdd(red_out + Cout + c, r2);
+    }
+}
+
+// Vector form of the backward reduction (materialised layout, L % 4 == 0; pooled layers need pool_k % 4 == 0 so the four
+// positions of a lane belong to one point).
+__global__ __launch_bounds__(TPB) void vn_bwd_reduce_vec_kernel(const float* __restrict__ PD, const float* __restrict__ gout,
+                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               int Cout, int Cd, int64_t L, int pool_k, float slope, int flags,
+                                                               double* __restrict__ red_out) {
+    __shared__ double red[16];
+    const int c = blockIdx.y, b = blockIdx.z;
+    const int Ctot = Cout + Cd;
+    const int cd = Cd == 1 ? Cout : Cout + c;
+    const bool act = flags & HPCS_VN_LRELU;
+    const float mu = mean[c], rs = rstd[c], ga = gamma[c], be = beta[c];
+    const float* pp = PD + (((int64_t)b * Ctot + c) * 3) * L;
+    const float* dp = PD + (((int64_t)b * Ctot + cd) * 3) * L;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < VEC_ITEMS; ++it) {
+        const int64_t l = ((int64_t)blockIdx.x * VEC_ITEMS + it) * (TPB * 4) + threadIdx.x * 4;
+        if (l < L) {
+            float pv[3][4], dv[3][4], gv[3][4];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float4 u = *reinterpret_cast<const float4*>(pp + a * L + l);
+                pv[a][0] = u.x; pv[a][1] = u.y; pv[a][2] = u.z; pv[a][3] = u.w;
+                if (act) {
+                    const float4 v = *reinterpret_cast<const float4*>(dp + a * L + l);
+                    dv[a][0] = v.x; dv[a][1] = v.y; dv[a][2] = v.z; dv[a][3] = v.w;
+                }
+            }
+            if (pool_k > 0) {
+                const int64_t Np = L / pool_k;
+                const float inv = 1.f / (float)pool_k;
+                const float* gp = gout + (((int64_t)b * Cout + c) * 3) * Np + l / pool_k;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const float g = gp[a * Np] * inv;
+                    gv[a][0] = g; gv[a][1] = g; gv[a][2] = g; gv[a][3] = g;
+                }
+            } else {
+                const float* gp = gout + (((int64_t)b * Cout + c) * 3) * L + l;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const float4 g = *reinterpret_cast<const float4*>(gp + a * L);
+                    gv[a][0] = g.x; gv[a][1] = g.y; gv[a][2] = g.z; gv[a][3] = g.w;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                VnPoint sp;
+                float g[3], gq[3], gd[3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    sp.p[a] = pv[a][q];
+                    sp.d[a] = act ? dv[a][q] : 0.f;
+                    g[a] = gv[a][q];
+                }
+                vn_forward_point(sp, mu, rs, ga, be, flags);
+                vn_lrelu_bwd_point(sp, g, slope, flags, gq, gd);
+                const float gnb = (gq[0] * sp.p[0] + gq[1] * sp.p[1] + gq[2] * sp.p[2]) / sp.n;
+                s1 += gnb;
+                s2 += gnb * sp.xhat;
+            }
         }
     }
     const double r1 = hpcs_block_sum<double>((double)s1, red);
@@ -1011,8 +1117,12 @@ extern "C" int hpcs_edge_gather_bwd(const float* gout, const int64_t* idx, int B
 static int vn_norm_stats_impl(PdRef pd, int B, int Cout, double* sums, int zeroed, hipStream_t st) {
     if (!zeroed && hipMemsetAsync(sums, 0, sizeof(double) * 2 * Cout, st) != hipSuccess) return HPCS_ERR_HIP;
     if (B == 0) return HPCS_OK;
-    hipLaunchKernelGGL(vn_norm_stats_kernel, dim3(hpcs_cdiv((int64_t)B * pd.L, TPB * ITEMS), Cout), dim3(TPB), 0, st, pd, B,
-                       pd.Ctot, pd.L, Cout, sums);
+    if (pd.idx == nullptr && pd.L % 4 == 0 && (((uintptr_t)pd.base & 15u) == 0) && B <= 65535 && Cout <= 65535)
+        hipLaunchKernelGGL(vn_norm_stats_vec_kernel, dim3(hpcs_cdiv(pd.L, TPB * 4 * VEC_ITEMS), Cout, B), dim3(TPB), 0, st, pd.base,
+                           pd.Ctot, pd.L, Cout, sums);
+    else
+        hipLaunchKernelGGL(vn_norm_stats_kernel, dim3(hpcs_cdiv((int64_t)B * pd.L, TPB * ITEMS), Cout), dim3(TPB), 0, st, pd, B,
+                           pd.Ctot, pd.L, Cout, sums);
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;
 }
@@ -1079,8 +1189,14 @@ static int vn_bwd_reduce_impl(PdRef pd, const float* gout, const float* mean, co
     if (!(flags & HPCS_VN_BN)) return HPCS_ERR_UNSUPPORTED;
     if (!zeroed && hipMemsetAsync(red, 0, sizeof(double) * 2 * Cout, st) != hipSuccess) return HPCS_ERR_HIP;
     if (B == 0) return HPCS_OK;
-    hipLaunchKernelGGL(vn_bwd_reduce_kernel, dim3(hpcs_cdiv((int64_t)B * pd.L, TPB * ITEMS), Cout), dim3(TPB), 0, st, pd, gout,
-                       mean, rstd, gamma, beta, B, Cout, Cd, pd.L, pool_k, slope, flags, red);
+    const bool vec = pd.idx == nullptr && pd.L % 4 == 0 && (((uintptr_t)pd.base & 15u) == 0) && B <= 65535 && Cout <= 65535 &&
+                     (pool_k > 0 ? pool_k % 4 == 0 : (((uintptr_t)gout & 15u) == 0));
+    if (vec)
+        hipLaunchKernelGGL(vn_bwd_reduce_vec_kernel, dim3(hpcs_cdiv(pd.L, TPB * 4 * VEC_ITEMS), Cout, B), dim3(TPB), 0, st, pd.base,
+                           gout, mean, rstd, gamma, beta, Cout, Cd, pd.L, pool_k, slope, flags, red);
+    else
+        hipLaunchKernelGGL(vn_bwd_reduce_kernel, dim3(hpcs_cdiv((int64_t)B * pd.L, TPB * ITEMS), Cout), dim3(TPB), 0, st, pd, gout,
+                           mean, rstd, gamma, beta, B, Cout, Cd, pd.L, pool_k, slope, flags, red);
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;
 }

@@ -15,11 +15,11 @@ class RAdam(torch.optim.Adam):
     def _tables(self, group, params):
         """Device tables (descriptors + row starts), rebuilt every step because the step sizes change.  Tensors whose
         points are one-dimensional (Conv1d weights [Co,Ci,1], `scale`) go to a table walked with one lane per row,
-        the others with eight lanes per row; the step sizes follow the reference's parameter order either way."""
+        rows of up to 64 columns with eight lanes per row, wider rows with a whole wave per row; the step sizes follow the reference's parameter order either way."""
         import struct
         b1, b2 = group["betas"]
         lr = group["lr"]
-        entries = {1: [], 8: []}
+        entries = {1: [], 8: [], 64: []}
         for p in params:
             st = self.state[p]
             group["step"] += 1
@@ -28,7 +28,7 @@ class RAdam(torch.optim.Adam):
             group["step"] += 1
             cols = p.shape[-1] if p.dim() > 0 else 1
             rows = p.numel() // cols
-            entries[1 if cols == 1 else 8].append(
+            entries[1 if cols == 1 else (8 if cols <= 64 else 64)].append(
                 (p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), rows, cols, step_size))
         out = []
         for lanes, ents in entries.items():

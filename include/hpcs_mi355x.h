@@ -271,7 +271,7 @@ int hpcs_triplet_margin_bwd(const float* xn, int E, const int64_t* a, const int6
  * (device pointers as uint64, rows*cols elements, `cols` = size of the last dim = the "point").
  * step_sizes[i] = lr*sqrt(1-b2^t)/(1-b1^t) with the reference's per-parameter double increment of
  * group["step"] (host-computed).  Applies egrad2rgrad, moment updates, expmap retraction, project
- * (row-norm clip 1-4e-3) and parallel transport of exp_avg.  lanes_per_row = 8 (vector points) or 1 (tables
+ * (row-norm clip 1-4e-3) and parallel transport of exp_avg.  lanes_per_row = 8 (vector points), 64 (wide rows: a wave per row) or 1 (tables
  * whose tensors all have cols == 1: same arithmetic, one lane per row). */
 typedef struct {
     uint64_t param, grad, exp_avg, exp_avg_sq;
