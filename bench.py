@@ -77,6 +77,22 @@ def pmc_traffic(kernel_substr):
     return round(sum(b * n for b, n in hit) / sum(n for _, n in hit))
 
 
+EXTRA_STEPS = 3
+EXTRA_NOTE = f"HIP events in {EXTRA_STEPS} further steps after the timed region"
+
+
+def is_small_gemm(tag):
+    """hpcs_gemm_tn's dispatch (gemm.hip): fewer than 32 tiles of 128x128 and a short reduction -> per-element kernel."""
+    M, Nc, K, no, ni = tag[7], tag[8], tag[9], tag[10], tag[11]
+    tiles = -(-M // 128) * -(-Nc // 128) * no * ni
+    return tiles < 32 and Nc >= 16 and K <= 4096
+
+
+def is_big_mfma_gemm(tag):
+    """launches of gemm_tn_kernel<128,128,16,2,2>"""
+    return tag[7] > 64 and not is_small_gemm(tag)
+
+
 def gemm_bytes(tag):
     M, Nc, K, no, ni = tag[7], tag[8], tag[9], tag[10], tag[11]
     return 4.0 * (M * K + (K + M) * Nc * no * ni)
@@ -195,7 +211,10 @@ def main():
     barrier()
     timed = not args.no_kernel_timing
     if timed:
-        _lib.PROFILE = {"hpcs_knn": [], "hpcs_gemm_tn": [], "hpcs_hyphc_bwd": [], "hpcs_hyphc_sampled": []}
+        # HIP events (on the launch stream) around every launch of the DOMINANT kernel only, live in the timed region:
+        # hpcs_gemm_tn calls that dispatch gemm_tn_kernel<128,128,16,2,2> (M > 64 and >= 32 tiles, see gemm.hip)
+        _lib.PROFILE = {"hpcs_gemm_tn": []}
+        _lib.PROFILE_FILTER = lambda name, tg: is_big_mfma_gemm(tg)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         losses = step.training_step(pts_d, cat_d, tgt_d, targets_host=tgt)
@@ -203,6 +222,18 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     prof, _lib.PROFILE = _lib.PROFILE, None
+    _lib.PROFILE_FILTER = None
+    prof_extra = {}
+    if timed:                  # every rank runs them: the step contains the gradient all-reduce
+        # the secondary kernels (EdgeConv GEMM, loss, kNN) are timed in EXTRA_STEPS further steps OUTSIDE the timed
+        # region, so that their event pairs do not perturb the reported throughput
+        _lib.PROFILE = {"hpcs_knn": [], "hpcs_gemm_tn": [], "hpcs_hyphc_bwd": [], "hpcs_hyphc_sampled": []}
+        for _ in range(EXTRA_STEPS):
+            step.training_step(pts_d, cat_d, tgt_d, targets_host=tgt)
+        torch.cuda.synchronize()
+        prof_extra, _lib.PROFILE = _lib.PROFILE, None
+    if world > 1:
+        dist.barrier()
     try:
         step._last_kept = int(step.metric_hyp_loss.last_kept.item())
     except Exception:
@@ -243,8 +274,10 @@ def main():
     if timed and prof:
         def dur(lst):
             return [(e0.elapsed_time(e1) * 1e-3, tag) for e0, e1, tag in lst]
-        kn = dur(prof["hpcs_knn"])
+        kn = dur(prof_extra["hpcs_knn"])
         gm = dur(prof["hpcs_gemm_tn"])
+        gm_extra = dur(prof_extra["hpcs_gemm_tn"])
+        dt_extra = dt / args.steps * EXTRA_STEPS          # step time scale for the shares of the extra-phase kernels
         B, N, k = args.batch, args.points, args.k
         # kNN: algorithmic bytes per launch = B*N*(4*D + 8*k)   (SURVEY 8d); tag = (B, D, N, k)
         kn_bytes = sum(t_[0] * t_[2] * (4 * t_[1] + 8 * t_[3]) for _, t_ in kn)
@@ -252,8 +285,8 @@ def main():
         kn_time = sum(d for d, _ in kn)
         # dominant kernel = gemm_tn_kernel<128,128,16,2,2>: every hpcs_gemm_tn launch with M > 64 (the M <= 64
         # EdgeConv launches run the HBM-bound <64,128,16,1,4> instantiation and are reported separately)
-        big = [(d, t_) for d, t_ in gm if t_[7] > 64]
-        small = [(d, t_) for d, t_ in gm if t_[7] <= 64]
+        big = [(d, t_) for d, t_ in gm if is_big_mfma_gemm(t_)]
+        small = [(d, t_) for d, t_ in gm_extra if t_[7] <= 64 and not is_small_gemm(t_)]
         gm_flops = sum(gemm_flops(t_) for _, t_ in big)
         gm_time = sum(d for d, _ in big)
         out["roofline"] = {"kernel": "gemm_tn_kernel<128,128,16,2,2> (hpcs_gemm_tn, M > 64: VN dense layers + heads, "
@@ -273,8 +306,8 @@ def main():
                                          "traffic": pmc_traffic("gemm_tn_kernel<64"),
                                          "algorithmic_bytes_per_launch": round(sb / len(small)), "launches": len(small),
                                          "avg_launch_us": round(1e6 * st_ / len(small), 2),
-                                         "share_of_step": round(st_ / dt, 4)}
-        hb = dur(prof.get("hpcs_hyphc_sampled", []) or prof.get("hpcs_hyphc_bwd", []))
+                                         "share_of_step": round(st_ / dt_extra, 4), "measured": EXTRA_NOTE}
+        hb = dur(prof_extra.get("hpcs_hyphc_sampled", []) or prof_extra.get("hpcs_hyphc_bwd", []))
         if hb:
             T_s = int(step.metric_hyp_loss.last_T)
             E_ = args.embedding
@@ -288,7 +321,8 @@ def main():
                                          "traffic": pmc_traffic("hyphc_sampled_kernel") or pmc_traffic("hyphc_kernel<4, true"),
                                          "algorithmic_bytes_per_launch": round(hb_bytes / len(hb)), "launches": len(hb),
                                          "avg_launch_us": round(1e6 * hb_time / len(hb), 2),
-                                         "share_of_step": round(hb_time / dt, 4), "triplets_sampled": T_s,
+                                         "share_of_step": round(hb_time / dt_extra, 4), "measured": EXTRA_NOTE,
+                                         "triplets_sampled": T_s,
                                          "triplets_kept": kept,
                                          "note": "float atomics run at ~1.3 TB/s of added bytes chip-wide (MI355X_MICROARCH)"}
         out["roofline_knn"] = {"kernel": "knn_sumsq_kernel + knn_mfma_kernel (hpcs_knn, D=3 and D=63 launches)",
@@ -297,7 +331,7 @@ def main():
                                "frac": round(kn_bytes / kn_time / 1e9 / HBM_PEAK_GBS, 5), "traffic": pmc_traffic("knn_mfma_kernel"),
                                "algorithmic_bytes_per_launch": round(kn_bytes / len(kn)),
                                "launches": len(kn), "avg_launch_us": round(1e6 * kn_time / len(kn), 2),
-                               "fp32_tflops": round(kn_flops / kn_time / 1e12, 3),
+                               "fp32_tflops": round(kn_flops / kn_time / 1e12, 3), "measured": EXTRA_NOTE,
                                "note": "arithmetic intensity 36-313 flop/B: bound by the VALU top-k selection, not by HBM"}
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args)

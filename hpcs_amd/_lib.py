@@ -104,22 +104,27 @@ def _dev_ptr(t):
 # Optional per-entry-point timing with events on the launch stream (bench.py's roofline leg).
 # PROFILE = {"hpcs_knn": [(start_event, end_event, tag), ...], ...}; only names present as keys are timed.
 PROFILE = None
+PROFILE_FILTER = None      # optional callable(name, shape_tag) -> bool: time only the launches it accepts
 
 
 def call(name, *args, tag=None):
     """Calls an entry point; tensors become device pointers, the stream argument is appended."""
     if PROFILE is not None and name in PROFILE:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        rc = _call(name, *args)
-        e1.record()
-        PROFILE[name].append((e0, e1, tag if tag is not None else _shape_tag(name, args)))
-        return rc
+        tg = tag if tag is not None else _shape_tag(name, args)
+        if PROFILE_FILTER is None or PROFILE_FILTER(name, tg):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = _call(name, *args)
+            e1.record()
+            PROFILE[name].append((e0, e1, tg))
+            return rc
     return _call(name, *args)
 
 
 def _shape_tag(name, args):
-    return tuple(a for a in args if isinstance(a, int) and not isinstance(a, bool))
+    """The integer (non-pointer) arguments of a call, in order (pointers may arrive as raw ints: skipped by kind)."""
+    kinds = [c for c in SIGNATURES[name][0] if c != "s"]
+    return tuple(a for c, a in zip(kinds, args) if c != "p" and isinstance(a, int) and not isinstance(a, bool))
 
 
 def _call(name, *args):
