@@ -160,14 +160,47 @@ def test_full_extractor_vs_reference(golden, E):
     close_but(y, ref, rtol=1e-4, atol=3e-5 * float(ref.abs().max()), max_outlier_frac=2e-3)
     net.train()
     xg = x.to(dev).requires_grad_(True)
-    y = net(xg, lab.to(dev))
+    from hpcs_amd import ops
+    graphs, real_knn = [], ops.knn
+
+    def recording_knn(xx, kk):                      # pins the three kNN graphs for the fp64 evaluation below
+        idx_ = real_knn(xx, kk)
+        graphs.append(idx_.cpu())
+        return idx_
+    ops.knn = recording_knn
+    try:
+        y = net(xg, lab.to(dev))
+    finally:
+        ops.knn = real_knn
     ref = T(golden[f"net_E{E}_train_out"])
     close_but(y, ref, rtol=1e-4, atol=5e-5 * float(ref.abs().max()), max_outlier_frac=2e-3)
-    (y * det_uniform(tuple(y.shape), 52).to(dev)).sum().backward()
-    # Gradient tolerance: in train mode the fp32 REFERENCE's own gradients sit 0.4-1.4% (L2) from an fp64
-    # evaluation of the same graph (13 batch-norms, measured in DESIGN.md "Gradient conditioning"); the HIP
-    # path is held to the same band against the reference.
-    GT = 1.5e-2
+    wsum = det_uniform(tuple(y.shape), 52)
+    (y * wsum.to(dev)).sum().backward()
+    # Gradient tolerances.  In train mode the fp32 REFERENCE's own gradients sit 0.4-1.4% (L2) from an fp64
+    # evaluation of the same graph (13 stacked batch-norms amplify every rounding; DESIGN.md "Gradient
+    # conditioning"), and so does any other fp32 evaluation order: the HIP path measures 1.0-2.0% from fp64 on the
+    # deepest layer's parameters (conv1), run to run and build to build.  So (a) the HIP path is held to 2.5e-2
+    # against the fp64 evaluation of the oracle on the SAME kNN graphs, and (b) to 3e-2 against the reference's fp32
+    # golden gradients, whose own distance from exact is part of that band.
+    assert len(graphs) == 3
+    P64 = OE.resolve_aliases({k_: (v.double() if v.is_floating_point() else v.clone()) for k_, v in sd.items()})
+    learn = [k_ for k_, v in P64.items() if v.is_floating_point() and "running" not in k_ and "num_batches" not in k_]
+    for k_ in learn:
+        P64[k_].requires_grad_(True)
+    OE.resolve_aliases(P64)
+    x64 = x.double().requires_grad_(True)
+    it = iter(graphs)
+    y64 = OE.vn_dgcnn_partseg(x64, lab.double(), P64, k=10, training=True, knn_fn=lambda xx, kk: next(it))
+    (y64 * wsum.double()).sum().backward()
+    relclose(xg.grad, x64.grad, 2.5e-2)
+    exact = 0
+    for n_, p_ in net.named_parameters():
+        g64 = P64[n_].grad if n_ in P64 else None
+        if g64 is not None and float(g64.norm()) > 0:
+            relclose(p_.grad, g64.reshape(p_.grad.shape), 2.5e-2)
+            exact += 1
+    assert exact >= 40
+    GT = 3e-2
     relclose(xg.grad, golden[f"net_E{E}_train_gx"], GT)
     checked = 0
     for n_, p_ in net.named_parameters():
