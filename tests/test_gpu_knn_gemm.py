@@ -33,6 +33,19 @@ def test_knn_bit_exact(B, D, N, k, seed):
     assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("kernel", ["tiled", "queue"])
+def test_knn_both_mfma_kernels_bit_exact(kernel, monkeypatch):
+    """The two MFMA selection kernels (interleaved 4-wave tiles / one wave with per-lane queues) are chosen by problem
+    size; both must reproduce the oracle on every shape, duplicates included."""
+    monkeypatch.setenv("HPCS_KNN_KERNEL", kernel)
+    for B, D, N, k, seed in [(2, 3, 256, 10, 31), (3, 3, 1024, 20, 32), (2, 63, 512, 20, 33), (1, 63, 2048, 40, 34),
+                             (2, 3, 100, 7, 35), (1, 3, 64, 33, 36)]:
+        x = det_cloud(B, N, seed) if D == 3 else det_normalish((B, D, N), seed)
+        assert torch.equal(hip_knn(x, k), OE.knn_exact(x, k)), (kernel, B, D, N, k)
+    x = det_cloud(2, 128, 37, dup_every=5)
+    assert torch.equal(hip_knn(x, 8), OE.knn_exact(x, 8))
+
+
 def test_knn_duplicates_and_golden(golden):
     x = det_cloud(2, 128, 13, dup_every=5)
     assert torch.equal(hip_knn(x, 8), OE.knn_exact(x, 8))
