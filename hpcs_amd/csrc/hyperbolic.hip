@@ -288,6 +288,26 @@ __global__ void colsum_kernel(const float* __restrict__ x, int64_t rows, int E, 
     }
 }
 
+// E a power of two <= 256: thread t owns column t % E and walks rows t / E, t / E + 256 / E, ... of a 256-row slab: every
+// wave instruction reads 256 contiguous bytes (the kernel above leaves half the lanes idle at E = 32 and walks 256
+// dependent loads per wave: 49 us at M = 32768 against 5 us here).
+__global__ __launch_bounds__(256) void colsum_pow2_kernel(const float* __restrict__ x, int64_t rows, int E,
+                                                        double* __restrict__ colsum) {
+    __shared__ double sh[256];
+    const int e = threadIdx.x % E, rsub = threadIdx.x / E, rpi = 256 / E;
+    const int64_t r0 = (int64_t)blockIdx.x * 256;
+    const int64_t r1 = r0 + 256 < rows ? r0 + 256 : rows;
+    double acc = 0.0;
+    for (int64_t r = r0 + rsub; r < r1; r += rpi) acc += (double)x[r * E + e];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < E) {
+        double t = 0.0;
+        for (int i = 0; i < rpi; ++i) t += sh[i * E + threadIdx.x];
+        atomicAdd(colsum + threadIdx.x, t);
+    }
+}
+
 }  // namespace
 
 #define ST ((hipStream_t)stream)
@@ -399,7 +419,10 @@ extern "C" int hpcs_colsum(const float* xn, int64_t rows, int E, double* colsum,
     if (!ROW_ARGS_OK(rows, E)) return HPCS_ERR_SHAPE;
     if (hipMemsetAsync(colsum, 0, sizeof(double) * E, ST) != hipSuccess) return HPCS_ERR_HIP;
     if (rows == 0) return HPCS_OK;
-    hipLaunchKernelGGL(colsum_kernel, dim3(hpcs_cdiv(E, 64), hpcs_cdiv(rows, 1024)), dim3(256), 0, ST, xn, rows, E, colsum);
+    if (E <= 256 && (E & (E - 1)) == 0)
+        hipLaunchKernelGGL(colsum_pow2_kernel, dim3(hpcs_cdiv(rows, 256)), dim3(256), 0, ST, xn, rows, E, colsum);
+    else
+        hipLaunchKernelGGL(colsum_kernel, dim3(hpcs_cdiv(E, 64), hpcs_cdiv(rows, 1024)), dim3(256), 0, ST, xn, rows, E, colsum);
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;
 }

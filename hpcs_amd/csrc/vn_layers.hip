@@ -1025,6 +1025,24 @@ __global__ void rowsum_kernel(const float* __restrict__ x, int64_t L, float scal
     if (threadIdx.x == 0) out[row] = t * scale;
 }
 
+// a few very long rows (e.g. the mean of 32768 per-row losses): 1024 threads, 16-byte loads
+__global__ __launch_bounds__(1024) void rowsum_long_kernel(const float* __restrict__ x, int64_t L, float scale,
+                                                          float* __restrict__ out) {
+    __shared__ float red[16];
+    const int64_t row = blockIdx.x;
+    const float* xr = x + row * L;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const int64_t L4 = L / 4;
+    for (int64_t q = threadIdx.x; q < L4; q += 1024) {
+        const float4 v = *reinterpret_cast<const float4*>(xr + 4 * q);
+        s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
+    }
+    float s = (s0 + s1) + (s2 + s3);
+    for (int64_t l = 4 * L4 + threadIdx.x; l < L; l += 1024) s += xr[l];
+    const float t = hpcs_block_sum<float>(s, red);
+    if (threadIdx.x == 0) out[row] = t * scale;
+}
+
 __global__ void vn_maxpool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ d, int C, int N, int k,
                                       float* __restrict__ out, int32_t* __restrict__ arg) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1468,7 +1486,10 @@ extern "C" int hpcs_rowsum(const float* x, int64_t rows, int64_t L, float scale,
     if (!x || !out) return HPCS_ERR_NULL;
     if (rows < 0 || L <= 0) return HPCS_ERR_SHAPE;
     if (rows == 0) return HPCS_OK;
-    hipLaunchKernelGGL(rowsum_kernel, dim3((unsigned)rows), dim3(L >= 256 ? 256 : 64), 0, ST, x, L, scale, out);
+    if (rows <= 64 && L >= 8192 && L % 4 == 0 && (((uintptr_t)x & 15u) == 0))
+        hipLaunchKernelGGL(rowsum_long_kernel, dim3((unsigned)rows), dim3(1024), 0, ST, x, L, scale, out);
+    else
+        hipLaunchKernelGGL(rowsum_kernel, dim3((unsigned)rows), dim3(L >= 256 ? 256 : 64), 0, ST, x, L, scale, out);
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;
 }
