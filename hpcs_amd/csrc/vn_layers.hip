@@ -1025,6 +1025,22 @@ __global__ void rowsum_kernel(const float* __restrict__ x, int64_t L, float scal
     if (threadIdx.x == 0) out[row] = t * scale;
 }
 
+// many medium rows (256 <= L, L % 4 == 0): one WAVE per row, 16-byte loads, no workgroup barrier
+__global__ __launch_bounds__(256) void rowsum_wave_kernel(const float* __restrict__ x, int64_t rows, int64_t L, float scale,
+                                                         float* __restrict__ out) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* xr = x + row * L;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int64_t q = lane; q < L / 4; q += 64) {
+        const float4 v = *reinterpret_cast<const float4*>(xr + 4 * q);
+        s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
+    }
+    const float t = hpcs_wave_sum((s0 + s1) + (s2 + s3));
+    if (lane == 0) out[row] = t * scale;
+}
+
 // a few very long rows (e.g. the mean of 32768 per-row losses): 1024 threads, 16-byte loads
 __global__ __launch_bounds__(1024) void rowsum_long_kernel(const float* __restrict__ x, int64_t L, float scale,
                                                           float* __restrict__ out) {
@@ -1488,6 +1504,8 @@ extern "C" int hpcs_rowsum(const float* x, int64_t rows, int64_t L, float scale,
     if (rows == 0) return HPCS_OK;
     if (rows <= 64 && L >= 8192 && L % 4 == 0 && (((uintptr_t)x & 15u) == 0))
         hipLaunchKernelGGL(rowsum_long_kernel, dim3((unsigned)rows), dim3(1024), 0, ST, x, L, scale, out);
+    else if (rows >= 1024 && L >= 256 && L % 4 == 0 && (((uintptr_t)x & 15u) == 0))
+        hipLaunchKernelGGL(rowsum_wave_kernel, dim3((unsigned)hpcs_cdiv(rows, 4)), dim3(256), 0, ST, x, rows, L, scale, out);
     else
         hipLaunchKernelGGL(rowsum_kernel, dim3((unsigned)rows), dim3(L >= 256 ? 256 : 64), 0, ST, x, L, scale, out);
     HPCS_CHECK_LAUNCH();
