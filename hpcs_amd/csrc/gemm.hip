@@ -341,12 +341,19 @@ NtPlan nt_plan(int M, int Kx, int Nc, int n_batch) {
     p.tile = (M > 512 && Kx > 512) ? 128 : 64;     // measured: 128x128 tiles only pay for the 682x682 layer
     p.tilesM = hpcs_cdiv(M, p.tile);
     p.tilesK = hpcs_cdiv(Kx, p.tile);
-    p.chunk = 2048;
-    {   // short reductions (row-oriented bias GEMMs): shrink the chunk until ~512 workgroups share the columns
+    // one output tile (EdgeConv weight gradients: M, K <= 64 over ~2 M columns): MFMA (102 us) and HBM (147 us) phases of a
+    // workgroup do not overlap, so more, shorter workgroups hide more: 1024-column chunks -> 8 workgroups per CU
+    // (measured 249 -> 224 us at K = 42, 216 -> 200 us at K = 21)
+    p.chunk = p.tilesM * p.tilesK == 1 ? 1024 : 2048;
+    {   // too few workgroups for the chip (row-oriented bias GEMMs, conv6 / head weight gradients with 1-2 units per
+        // cloud): shrink the chunk until ~2048 workgroups share the columns, as long as the split partials
+        // (nsplit * M * Kx floats) stay small
         const long tiles = (long)p.tilesM * p.tilesK;
         const long units0 = (long)n_batch * hpcs_cdiv(Nc, p.chunk);
-        if (units0 * tiles < 256) {
-            const long target_units = 512 / tiles > 0 ? 512 / tiles : 1;
+        const long split_cap = (8L << 20) / ((long)M * Kx);              // partial buffer <= 32 MB
+        if (units0 * tiles < 1536 && split_cap > units0) {
+            long target_units = 2048 / tiles > 0 ? 2048 / tiles : 1;
+            if (target_units > split_cap) target_units = split_cap;
             long c = hpcs_cdiv((int64_t)Nc * n_batch, target_units);
             c = (c + 31) / 32 * 32;
             if (c < 64) c = 64;
