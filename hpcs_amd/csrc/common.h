@@ -25,6 +25,21 @@ __device__ __forceinline__ unsigned hpcs_xcd_remap(unsigned id, unsigned total) 
     return base + slot;
 }
 
+// 32-bit counter hash (two murmur3-style finalizer rounds over a 64-bit counter) and the inverted-dropout multiplier
+// derived from it: element `off` of a tensor is kept with probability 1 - p and scaled by 1 / (1 - p).  The same
+// (seed, off) gives the same value in forward and backward, so the mask never exists in memory.
+__device__ __forceinline__ unsigned hpcs_hash32(unsigned a, unsigned b) {
+    unsigned h = a * 0xCC9E2D51u + (b ^ 0x1B873593u);
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    h += b * 0x9E3779B1u;
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+    return h;
+}
+__device__ __forceinline__ float hpcs_dropout_mult(unsigned long long seed, long long off, unsigned thresh24, float inv_keep) {
+    const unsigned h = hpcs_hash32((unsigned)off ^ (unsigned)seed, (unsigned)((unsigned long long)off >> 32) ^ (unsigned)(seed >> 32));
+    return (h >> 8) >= thresh24 ? inv_keep : 0.f;
+}
+
 __device__ __forceinline__ float hpcs_wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

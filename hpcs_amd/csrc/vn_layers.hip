@@ -933,7 +933,8 @@ __global__ void bn_stats_kernel(const float* __restrict__ Y, int B, int C, int64
 __global__ void bn_act_fwd_kernel(const float* __restrict__ Y, const float* __restrict__ mean,
                                   const float* __restrict__ rstd, const float* __restrict__ gamma,
                                   const float* __restrict__ beta, const float* __restrict__ mask, int B, int C, int64_t L,
-                                  float slope, float* __restrict__ out) {
+                                  float slope, float* __restrict__ out, unsigned long long dseed, unsigned dthr,
+                                  float dinv) {
     const int c = blockIdx.y;
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (int64_t)B * L) return;
@@ -941,6 +942,7 @@ __global__ void bn_act_fwd_kernel(const float* __restrict__ Y, const float* __re
     const float z = (Y[off] - mean[c]) * rstd[c] * gamma[c] + beta[c];
     float o = z > 0.f ? z : z * slope;
     if (mask) o *= mask[off];
+    else if (dthr) o *= hpcs_dropout_mult(dseed, off, dthr, dinv);
     out[off] = o;
 }
 
@@ -948,7 +950,7 @@ __global__ void bn_act_bwd_reduce_kernel(const float* __restrict__ Y, const floa
                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                          const float* __restrict__ mask, int B, int C, int64_t L, float slope,
-                                         double* __restrict__ red_out) {
+                                         double* __restrict__ red_out, unsigned long long dseed, unsigned dthr, float dinv) {
     __shared__ double red[16];
     const int c = blockIdx.y;
     const int64_t total = (int64_t)B * L;
@@ -964,6 +966,7 @@ __global__ void bn_act_bwd_reduce_kernel(const float* __restrict__ Y, const floa
             const float z = xh * ga + be;
             float g = gout[off];
             if (mask) g *= mask[off];
+            else if (dthr) g *= hpcs_dropout_mult(dseed, off, dthr, dinv);
             g *= z > 0.f ? 1.f : slope;
             s1 += g;
             s2 += g * xh;
@@ -981,7 +984,8 @@ __global__ void bn_act_bwd_apply_kernel(const float* __restrict__ Y, const float
                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                         const float* __restrict__ mask, const double* __restrict__ red, int training,
-                                        int B, int C, int64_t L, float slope, float* __restrict__ gY) {
+                                        int B, int C, int64_t L, float slope, float* __restrict__ gY,
+                                        unsigned long long dseed, unsigned dthr, float dinv) {
     const int c = blockIdx.y;
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (int64_t)B * L) return;
@@ -992,6 +996,7 @@ __global__ void bn_act_bwd_apply_kernel(const float* __restrict__ Y, const float
     const float z = xh * ga + beta[c];
     float g = gout[off];
     if (mask) g *= mask[off];
+    else if (dthr) g *= hpcs_dropout_mult(dseed, off, dthr, dinv);
     g *= z > 0.f ? 1.f : slope;
     float r;
     if (training) {
@@ -1001,6 +1006,12 @@ __global__ void bn_act_bwd_apply_kernel(const float* __restrict__ Y, const float
         r = rs * ga * g;
     }
     gY[off] = r;
+}
+
+// the multiplier tensor the bn_act kernels apply implicitly for (seed, p): element i = 1/(1-p) or 0 (tests, debugging)
+__global__ void dropout_mask_kernel(unsigned long long seed, unsigned thr, float inv, int64_t n, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = thr ? hpcs_dropout_mult(seed, i, thr, inv) : 1.f;
 }
 
 // ------------------------------------------------------------------------------ glue
@@ -1622,39 +1633,57 @@ extern "C" int hpcs_bn_stats(const float* Y, int B, int C, int64_t L, double* su
     return HPCS_OK;
 }
 
+// dropout by counter hash (mask == NULL and 0 < drop_p < 1): keep iff hash24(seed, element offset) >= p * 2^24
+static inline unsigned drop_thresh(float p) { return p > 0.f && p < 1.f ? (unsigned)(p * 16777216.0f + 0.5f) : 0u; }
+static inline float drop_inv(float p) { return p > 0.f && p < 1.f ? 1.0f / (1.0f - p) : 1.0f; }
+
 extern "C" int hpcs_bn_act_fwd(const float* Y, const float* mean, const float* rstd, const float* gamma,
-                               const float* beta, const float* mask, int B, int C, int64_t L, float slope, float* out,
-                               hpcs_stream_t stream) {
+                               const float* beta, const float* mask, uint64_t drop_seed, float drop_p, int B, int C, int64_t L,
+                               float slope, float* out, hpcs_stream_t stream) {
     if (!Y || !mean || !rstd || !gamma || !beta || !out) return HPCS_ERR_NULL;
     if (bad_dims(B, C, L) || C > 65535) return HPCS_ERR_SHAPE;
     if (B == 0) return HPCS_OK;
     hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(hpcs_cdiv((int64_t)B * L, TPB), C), dim3(TPB), 0, ST, Y, mean, rstd, gamma,
-                       beta, mask, B, C, L, slope, out);
+                       beta, mask, B, C, L, slope, out, (unsigned long long)drop_seed, drop_thresh(drop_p), drop_inv(drop_p));
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;
 }
 
 extern "C" int hpcs_bn_act_bwd_reduce(const float* Y, const float* gout, const float* mean, const float* rstd,
-                                      const float* gamma, const float* beta, const float* mask, int B, int C, int64_t L,
-                                      float slope, double* red, int red_zeroed, hpcs_stream_t stream) {
+                                      const float* gamma, const float* beta, const float* mask, uint64_t drop_seed,
+                                      float drop_p, int B, int C, int64_t L, float slope, double* red, int red_zeroed,
+                                      hpcs_stream_t stream) {
     if (!Y || !gout || !mean || !rstd || !gamma || !beta || !red) return HPCS_ERR_NULL;
     if (bad_dims(B, C, L) || C > 65535) return HPCS_ERR_SHAPE;
     if (!red_zeroed && hipMemsetAsync(red, 0, sizeof(double) * 2 * C, ST) != hipSuccess) return HPCS_ERR_HIP;
     if (B == 0) return HPCS_OK;
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(hpcs_cdiv((int64_t)B * L, TPB * ITEMS), C), dim3(TPB), 0, ST, Y, gout,
-                       mean, rstd, gamma, beta, mask, B, C, L, slope, red);
+                       mean, rstd, gamma, beta, mask, B, C, L, slope, red, (unsigned long long)drop_seed, drop_thresh(drop_p),
+                       drop_inv(drop_p));
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;
 }
 
 extern "C" int hpcs_bn_act_bwd_apply(const float* Y, const float* gout, const float* mean, const float* rstd,
-                                     const float* gamma, const float* beta, const float* mask, const double* red,
-                                     int training, int B, int C, int64_t L, float slope, float* gY, hpcs_stream_t stream) {
+                                     const float* gamma, const float* beta, const float* mask, uint64_t drop_seed,
+                                     float drop_p, const double* red, int training, int B, int C, int64_t L, float slope,
+                                     float* gY, hpcs_stream_t stream) {
     if (!Y || !gout || !mean || !rstd || !gamma || !beta || !gY || (training && !red)) return HPCS_ERR_NULL;
     if (bad_dims(B, C, L) || C > 65535) return HPCS_ERR_SHAPE;
     if (B == 0) return HPCS_OK;
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(hpcs_cdiv((int64_t)B * L, TPB), C), dim3(TPB), 0, ST, Y, gout, mean,
-                       rstd, gamma, beta, mask, red, training, B, C, L, slope, gY);
+                       rstd, gamma, beta, mask, red, training, B, C, L, slope, gY, (unsigned long long)drop_seed,
+                       drop_thresh(drop_p), drop_inv(drop_p));
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
+extern "C" int hpcs_dropout_mask(uint64_t drop_seed, float drop_p, int64_t n, float* out, hpcs_stream_t stream) {
+    if (!out) return HPCS_ERR_NULL;
+    if (n < 0 || !(drop_p >= 0.f && drop_p < 1.f)) return HPCS_ERR_SHAPE;
+    if (n == 0) return HPCS_OK;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(hpcs_cdiv(n, TPB)), dim3(TPB), 0, ST, (unsigned long long)drop_seed,
+                       drop_thresh(drop_p), drop_inv(drop_p), n, out);
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;
 }

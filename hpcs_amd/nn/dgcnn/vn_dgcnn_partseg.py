@@ -25,6 +25,7 @@ class VN_DGCNN_partseg(nn.Module):
         self.out_features = out_features
         self.k = k
         self.dropout = dropout
+        self._drop_seed, self._drop_calls = None, 0
         self.pooling = pooling
         self.num_categories = num_categories
         c, g = 64 // 3, 1024 // 3
@@ -87,21 +88,28 @@ class VN_DGCNN_partseg(nn.Module):
             return convs[-1](e, pool_k=self.k)            # fused mean over the k neighbours
         return pool(convs[-1](e))
 
-    def _head(self, seq, x, rowbias=None, mask=None):
+    def _head(self, seq, x, rowbias=None, mask=None, drop=None):
         conv, bn = seq[0], seq[1]
         y = ops.chan_mix(x, conv.weight[:, :, 0], rowbias, sink=(conv.weight, (slice(None), slice(None), 0)))
         slope = 0.2 if len(seq) > 2 else 1.0
-        out = ops.bn_act(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training, slope, mask)
+        out = ops.bn_act(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training, slope, mask, drop)
         if self.training:
             bump(bn)
         return out
 
-    def _drop_mask(self, like, p, given):
+    def _dropout(self, p, given):
+        """(mask, drop) for ops.bn_act: an explicit multiplier tensor when the caller supplies one (parity tests), else
+        (seed, p) for the in-kernel counter RNG -- the mask of nn.Dropout (vn_dgcnn_partseg.py:46,50) is never stored.
+        The seed stream is (torch.initial_seed() at first use, running call counter): reproducible under
+        torch.manual_seed, statistically equivalent to torch's Philox stream, not bit-identical to it."""
         if given is not None:
-            return given
+            return given, None
         if not self.training or p <= 0.0:
-            return None
-        return torch.empty_like(like).bernoulli_(1.0 - p).div_(1.0 - p)
+            return None, None
+        if self._drop_seed is None:
+            self._drop_seed = int(torch.initial_seed()) & (2 ** 62 - 1)
+        self._drop_calls += 1
+        return None, (self._drop_seed + 0x9E3779B97F4A7C15 * self._drop_calls, p)
 
     # ---- forward -----------------------------------------------------------------------------------------
     def forward(self, x, l, drop_masks=None):
@@ -138,12 +146,12 @@ class VN_DGCNN_partseg(nn.Module):
         bias8 = ops.row_linear(vec, W8[:, :gc], sink=(W8p, (slice(None), slice(0, gc), 0)))  # [B,256]
         y8 = ops.chan_mix(loc, W8[:, gc:], bias8, sink=(W8p, (slice(None), slice(gc, None), 0)))
         bn = self.bn8
-        m1 = self._drop_mask(y8, self.dropout, None if drop_masks is None else drop_masks[0])
-        hh = ops.bn_act(y8, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training, 0.2, m1)
+        m1, d1 = self._dropout(self.dropout, None if drop_masks is None else drop_masks[0])
+        hh = ops.bn_act(y8, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training, 0.2, m1, d1)
         if self.training:
             bump(bn)
-        m2 = self._drop_mask(hh, self.dropout, None if drop_masks is None else drop_masks[1])
-        hh = self._head(self.conv9, hh, mask=m2)
+        m2, d2 = self._dropout(self.dropout, None if drop_masks is None else drop_masks[1])
+        hh = self._head(self.conv9, hh, mask=m2, drop=d2)
         hh = self._head(self.conv10, hh)
         hh = self._head(self.conv11, hh)
         return hh.transpose(1, 2)

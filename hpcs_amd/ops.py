@@ -636,8 +636,11 @@ class BnActFn(torch.autograd.Function):
     """BatchNorm1d over [B,C,L] (+ LeakyReLU(slope)) (* mask)."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, rmean, rvar, training, slope, mask):
+    def forward(ctx, y, gamma, beta, rmean, rvar, training, slope, mask, drop=None):
+        """mask: explicit [B,C,L] multiplier; drop = (seed, p): the multiplier is generated inside the kernels."""
         ctx.bnparams = (gamma, beta)
+        dseed, dp = (int(drop[0]) & (2 ** 63 - 1), float(drop[1])) if (drop is not None and mask is None) else (0, 0.0)
+        ctx.drop = (dseed, dp)
         y = _f32c(y)
         B, C = y.shape[0], y.shape[1]
         L = y[0, 0].numel()
@@ -650,7 +653,7 @@ class BnActFn(torch.autograd.Function):
             call("hpcs_bn_stats", y, B, C, L, sums, 1)
         call("hpcs_bn_finalize", sums, C, B * L, BN_EPS, BN_MOMENTUM, rmean, rvar, mean, rstd, 1 if training else 0)
         out = torch.empty_like(y)
-        call("hpcs_bn_act_fwd", y, mean, rstd, gamma, beta, mask, B, C, L, slope, out)
+        call("hpcs_bn_act_fwd", y, mean, rstd, gamma, beta, mask, dseed, dp, B, C, L, slope, out)
         ctx.save_for_backward(y, mean, rstd, gamma, beta, mask)
         ctx.cfg = (B, C, L, slope, bool(training))
         return out
@@ -661,16 +664,25 @@ class BnActFn(torch.autograd.Function):
         B, C, L, slope, training = ctx.cfg
         g = _f32c(g)
         red = _zeros64(2 * C, g.device)
-        call("hpcs_bn_act_bwd_reduce", y, g, mean, rstd, gamma, beta, mask, B, C, L, slope, red, 1)
+        dseed, dp = ctx.drop
+        call("hpcs_bn_act_bwd_reduce", y, g, mean, rstd, gamma, beta, mask, dseed, dp, B, C, L, slope, red, 1)
         gy = torch.empty_like(y)
-        call("hpcs_bn_act_bwd_apply", y, g, mean, rstd, gamma, beta, mask, red, 1 if training else 0, B, C, L, slope, gy)
+        call("hpcs_bn_act_bwd_apply", y, g, mean, rstd, gamma, beta, mask, dseed, dp, red, 1 if training else 0, B, C, L, slope,
+             gy)
         ggamma, gbeta = _bn_grads(ctx.bnparams, red, C, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
-        return gy, ggamma, gbeta, None, None, None, None, None
+        return gy, ggamma, gbeta, None, None, None, None, None, None
 
 
-def bn_act(y, gamma, beta, rmean, rvar, training, slope=0.2, mask=None):
+def bn_act(y, gamma, beta, rmean, rvar, training, slope=0.2, mask=None, drop=None):
     _need_cuda(y)
-    return BnActFn.apply(y, gamma, beta, rmean, rvar, training, slope, mask)
+    return BnActFn.apply(y, gamma, beta, rmean, rvar, training, slope, mask, drop)
+
+
+def dropout_mask(seed, p, shape, device):
+    """The multiplier tensor that bn_act(..., drop=(seed, p)) applies implicitly (tests)."""
+    out = torch.empty(shape, device=device, dtype=torch.float32)
+    call("hpcs_dropout_mask", int(seed) & (2 ** 63 - 1), float(p), out.numel(), out)
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ glue ops

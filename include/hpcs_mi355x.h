@@ -140,16 +140,22 @@ int hpcs_edge_grad_reduce(const float* GPD, const int64_t* idx, int B, int Ctot,
 
 /* ---- Conv1d(k=1)+BatchNorm1d(+LeakyReLU)(+Dropout mask)  vn_dgcnn_partseg.py:40-57,97-102 ------
  * Y [B,C,L] is the Conv1d output (hpcs_gemm_tn).  slope = 1 means no activation; mask (nullable,
- * [B,C,L]) is the already scaled dropout multiplier. */
+ * [B,C,L]) is the already scaled dropout multiplier.  With mask == NULL and 0 < drop_p < 1 the multiplier is
+ * generated in the kernels from a counter hash of (drop_seed, element offset): the same call arguments give the
+ * same mask in forward and backward, so it is never stored (nn.Dropout, vn_dgcnn_partseg.py:46,50). */
 int hpcs_bn_stats(const float* Y, int B, int C, int64_t L, double* sums, int sums_zeroed, hpcs_stream_t stream);
 int hpcs_bn_act_fwd(const float* Y, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                    const float* mask, int B, int C, int64_t L, float slope, float* out, hpcs_stream_t stream);
+                    const float* mask, uint64_t drop_seed, float drop_p, int B, int C, int64_t L, float slope, float* out,
+                    hpcs_stream_t stream);
 int hpcs_bn_act_bwd_reduce(const float* Y, const float* gout, const float* mean, const float* rstd,
-                           const float* gamma, const float* beta, const float* mask, int B, int C, int64_t L,
-                           float slope, double* red, int red_zeroed, hpcs_stream_t stream);
+                           const float* gamma, const float* beta, const float* mask, uint64_t drop_seed, float drop_p,
+                           int B, int C, int64_t L, float slope, double* red, int red_zeroed, hpcs_stream_t stream);
 int hpcs_bn_act_bwd_apply(const float* Y, const float* gout, const float* mean, const float* rstd,
-                          const float* gamma, const float* beta, const float* mask, const double* red,
-                          int training, int B, int C, int64_t L, float slope, float* gY, hpcs_stream_t stream);
+                          const float* gamma, const float* beta, const float* mask, uint64_t drop_seed, float drop_p,
+                          const double* red, int training, int B, int C, int64_t L, float slope, float* gY,
+                          hpcs_stream_t stream);
+/* The multiplier tensor that (drop_seed, drop_p) stands for: out[i] = 1/(1-p) or 0 (parity tests). */
+int hpcs_dropout_mask(uint64_t drop_seed, float drop_p, int64_t n, float* out, hpcs_stream_t stream);
 
 /* ---- a4/a5/a6 glue of VN_DGCNN_partseg.forward  vn_dgcnn_partseg.py:79-95 ---------------------
  * concat_mean   : x [B,C,3,N] -> out [B,2C,3,N] = (x, mean_N(x) expanded)          (:82-83)

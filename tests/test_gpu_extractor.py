@@ -449,3 +449,26 @@ def test_fused_edge_backward_equals_unfused(Cin, pool):
         res.append([xg.grad.clone()] + [p.grad.clone() for p in layer.parameters()])
     for a, b in zip(*res):
         relclose(a, b, 2e-5)
+
+
+def test_in_kernel_dropout_equals_explicit_mask():
+    """bn_act(drop=(seed, p)) -- the multiplier generated inside the three kernels -- equals bn_act(mask=) with the tensor
+    hpcs_dropout_mask materialises for the same (seed, p), forward and backward; keep rate and scale are right."""
+    from hpcs_amd import ops
+    B, C, L, p, seed = 3, 40, 500, 0.5, 123456789
+    y0 = det_normalish((B, C, L), 970)
+    gam, bet = det_uniform((C,), 971) + 1.5, det_uniform((C,), 972)
+    mask = ops.dropout_mask(seed, p, (B, C, L), dev)
+    keep = float((mask > 0).float().mean())
+    assert abs(keep - (1 - p)) < 0.02 and set(mask.unique().tolist()) == {0.0, 2.0}
+    assert not torch.equal(mask, ops.dropout_mask(seed + 1, p, (B, C, L), dev))
+    res = []
+    for use_mask in (True, False):
+        yg = y0.to(dev).requires_grad_(True)
+        g_, b_ = gam.to(dev).requires_grad_(True), bet.to(dev).requires_grad_(True)
+        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        out = ops.bn_act(yg, g_, b_, rm, rv, True, 0.2, mask if use_mask else None, None if use_mask else (seed, p))
+        (out * det_uniform((B, C, L), 973).to(dev)).sum().backward()
+        res.append((out.detach(), yg.grad, g_.grad, b_.grad))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
