@@ -627,7 +627,7 @@ __global__ __launch_bounds__(SB_THREADS) void hyphc_sampled_kernel(
     constexpr int TS = E + 8;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* cache = smem;                                            // [RC][TS]  (GRAD only)
-    float* stage = smem + (GRAD ? (size_t)RC * TS : 0);             // [waves][8][LD] negative-row transposition slab
+    float* stage = smem + (GRAD ? (size_t)RC * TS : 0);             // [waves][16][LD] negative-row ring + [waves][16] row ids
     __shared__ double red[16];
     __shared__ int cb_sh[3];
 
@@ -665,6 +665,10 @@ __global__ __launch_bounds__(SB_THREADS) void hyphc_sampled_kernel(
 #pragma unroll
     for (int j = 0; j < EPL; ++j) acc_a[j] = 0.f;
 
+    // wave-private ring of pending negative-row gradients (GRAD only)
+    float* qrows = stage + (threadIdx.x >> 6) * (16 * LD);
+    int* qid = reinterpret_cast<int*>(stage + (SB_THREADS / 64) * (16 * LD)) + (threadIdx.x >> 6) * 16;
+    int qh = 0, qn = 0;
     for (int b8 = 0; b8 < seg_len / SUB; ++b8) {
         // ---- lane s generates triplet (seg + 8*b8 + s): eight index chains in flight per group --------------------
         const int64_t tl = seg + b8 * SUB + s;
@@ -702,19 +706,30 @@ __global__ __launch_bounds__(SB_THREADS) void hyphc_sampled_kernel(
         // ---- phase A: the group walks its 8 triplets for the three dot products; lane j keeps those of triplet j.
         // Per-triplet values travel down the group by one lane per step, so every broadcast has a constant source lane;
         // the rows of the next triplet are in flight during the math of the current one.
-        float av[EPL], pv[EPL], nv[EPL], av2[EPL], pv2[EPL], nv2[EPL];
+        float av[EPL], pv[EPL], nv[EPL], av2[EPL], pv2[EPL], nv2[EPL], pv3[EPL], nv3[EPL];
         float D1 = 0.f, D2 = 0.f, D3 = 0.f;
+        // The anchor changes once per ~k_c consecutive triplets: its row is fetched only when it does (the kernel is bound
+        // by these 128-byte L2 gathers: 3 rows per triplet per phase).
         {
             int ia_sh = ia_own, ip_sh = ip_own, in_sh = in_own;
-            IO::load(xn, E, grp_bcast<0>(ia_sh), s, av);
+            int ia_c = grp_bcast<0>(ia_sh);
+            IO::load(xn, E, ia_c, s, av);
             IO::load(xn, E, grp_bcast<0>(ip_sh), s, pv);
             IO::load(xn, E, grp_bcast<0>(in_sh), s, nv);
+            IO::load(xn, E, grp_bcast<1>(ip_sh), s, pv2);              // two triplets ahead: the gathers' L2 latency is
+            IO::load(xn, E, grp_bcast<1>(in_sh), s, nv2);              // longer than one triplet's arithmetic
 #pragma unroll 1
             for (int j8 = 0; j8 < SUB; ++j8) {
+                bool a_new = false;
                 if (j8 + 1 < SUB) {
-                    IO::load(xn, E, grp_bcast<1>(ia_sh), s, av2);
-                    IO::load(xn, E, grp_bcast<1>(ip_sh), s, pv2);
-                    IO::load(xn, E, grp_bcast<1>(in_sh), s, nv2);
+                    const int ia_n = grp_bcast<1>(ia_sh);
+                    a_new = ia_n != ia_c;
+                    ia_c = ia_n;
+                    if (a_new) IO::load(xn, E, ia_n, s, av2);
+                }
+                if (j8 + 2 < SUB) {
+                    IO::load(xn, E, grp_bcast<2>(ip_sh), s, pv3);
+                    IO::load(xn, E, grp_bcast<2>(in_sh), s, nv3);
                 }
                 float d1 = 0.f, d2 = 0.f, d3 = 0.f;
 #pragma unroll
@@ -732,7 +747,11 @@ __global__ __launch_bounds__(SB_THREADS) void hyphc_sampled_kernel(
                 D3 = mine ? d3 : D3;
                 ia_sh = grp_shift_down(ia_sh); ip_sh = grp_shift_down(ip_sh); in_sh = grp_shift_down(in_sh);
 #pragma unroll
-                for (int j = 0; j < EPL; ++j) { av[j] = av2[j]; pv[j] = pv2[j]; nv[j] = nv2[j]; }
+                for (int j = 0; j < EPL; ++j) {
+                    av[j] = a_new ? av2[j] : av[j];
+                    pv[j] = pv2[j]; nv[j] = nv2[j];
+                    pv2[j] = pv3[j]; nv2[j] = nv3[j];
+                }
             }
         }
         // ---- phase B: every lane does the scalar part of ITS triplet (three LCA distances, the softmax, the weights)
@@ -761,20 +780,30 @@ __global__ __launch_bounds__(SB_THREADS) void hyphc_sampled_kernel(
             int ia_sh = ia_own, ip_sh = ip_own, in_sh = in_own;
             int cp_sh = live ? cpos_own : -2;                            // -2: dropped triplet, -1: positive not tabled
             int c0_sh = __float_as_int(c0_own), c1_sh = __float_as_int(c1_own), c2_sh = __float_as_int(c2_own);
+            // rows are fetched only for kept triplets, and the anchor's only when it changes
             int ia = grp_bcast<0>(ia_sh), ip = grp_bcast<0>(ip_sh), in = grp_bcast<0>(in_sh);
-            IO::load(xn, E, ia, s, av);
-            IO::load(xn, E, ip, s, pv);
-            IO::load(xn, E, in, s, nv);
+            int ia_have = -1;                                             // anchor whose row sits in av
+            if (grp_bcast<0>(cp_sh) > -2) {
+                IO::load(xn, E, ia, s, av);
+                IO::load(xn, E, ip, s, pv);
+                IO::load(xn, E, in, s, nv);
+                ia_have = ia;
+            }
 #pragma unroll 1
             for (int j8 = 0; j8 < SUB; ++j8) {
                 int ia2 = 0, ip2 = 0, in2 = 0;
+                bool a_new = false, pn_new = false;
                 if (j8 + 1 < SUB) {
                     ia2 = grp_bcast<1>(ia_sh);
                     ip2 = grp_bcast<1>(ip_sh);
                     in2 = grp_bcast<1>(in_sh);
-                    IO::load(xn, E, ia2, s, av2);
-                    IO::load(xn, E, ip2, s, pv2);
-                    IO::load(xn, E, in2, s, nv2);
+                    pn_new = grp_bcast<1>(cp_sh) > -2;
+                    a_new = pn_new && ia2 != ia_have;
+                    if (a_new) IO::load(xn, E, ia2, s, av2);
+                    if (pn_new) {
+                        IO::load(xn, E, ip2, s, pv2);
+                        IO::load(xn, E, in2, s, nv2);
+                    }
                 }
                 const int cpos = grp_bcast<0>(cp_sh);
                 const bool lv = cpos > -2;
@@ -801,32 +830,54 @@ __global__ __launch_bounds__(SB_THREADS) void hyphc_sampled_kernel(
                         for (int j = 0; j < EPL; ++j) atomicAdd(gxn + (unsigned)(ip * E + s * EPL + j), c0 * av[j] + c2 * nv[j]);
                     }
                 }
-                // negative rows: whole contiguous rows per atomic wave-instruction via the wave-private slab
-                float* slab = stage + (threadIdx.x >> 6) * (8 * LD);
-                const int gi = lane >> 3;
+                // negative rows: a CU issues one 256-byte atomic wave-instruction per ~120 cycles, and this kernel is bound by
+                // exactly that.  Kept rows are therefore packed into a wave-private LDS ring (16 rows) and leave in groups
+                // of eight: 64 / E rows per instruction, every instruction full (pairing the rows of the current step
+                // left a third of the instructions half empty).
+                {
+                    const unsigned long long lbal = __ballot(lv);                 // all 8 lanes of a kept group are set
+                    const int n_live = __popcll(lbal) >> 3;
+                    if (lv) {
+                        const int rank = __popcll(lbal & ((1ull << (lane & ~7)) - 1ull)) >> 3;
+                        const int slot = (qh + qn + rank) & 15;
+                        float* qr = qrows + slot * LD + s * EPL;
 #pragma unroll
-                for (int j = 0; j < EPL; ++j) slab[gi * LD + s * EPL + j] = lv ? c1 * av[j] + c2 * pv[j] : 0.f;
-                __builtin_amdgcn_s_waitcnt(0xC07F);
-                constexpr int RPI = 64 / E;
-                const int in_live = lv ? in : -1;                    // uniform inside a group: read through v_readlane
-#pragma unroll
-                for (int r = 0; r < EPL; ++r) {
-                    const int tw = r * RPI + lane / E, e = lane % E;
-                    int rn = __builtin_amdgcn_readlane(in_live, (r * RPI) * SUB);
-#pragma unroll
-                    for (int q = 1; q < RPI; ++q) {
-                        const int v = __builtin_amdgcn_readlane(in_live, (r * RPI + q) * SUB);
-                        rn = lane / E == q ? v : rn;
+                        for (int j = 0; j < EPL; ++j) qr[j] = c1 * av[j] + c2 * pv[j];
+                        if (s == 0) qid[slot] = in;
                     }
-                    if (rn >= 0) atomicAdd(gxn + (unsigned)(rn * E + e), slab[tw * LD + e]);
+                    qn += n_live;
+                    if (qn >= 8) {
+                        constexpr int RPI = 64 / E;
+#pragma unroll
+                        for (int r = 0; r < EPL; ++r) {
+                            const int slot = (qh + r * RPI + lane / E) & 15, e = lane % E;
+                            atomicAdd(gxn + (unsigned)(qid[slot] * E + e), qrows[slot * LD + e]);
+                        }
+                        qh = (qh + 8) & 15;
+                        qn -= 8;
+                    }
                 }
                 ia = ia2; ip = ip2; in = in2;
                 ia_sh = grp_shift_down(ia_sh); ip_sh = grp_shift_down(ip_sh); in_sh = grp_shift_down(in_sh);
                 cp_sh = grp_shift_down(cp_sh);
                 c0_sh = grp_shift_down(c0_sh); c1_sh = grp_shift_down(c1_sh); c2_sh = grp_shift_down(c2_sh);
+                if (a_new) ia_have = ia2;
 #pragma unroll
-                for (int j = 0; j < EPL; ++j) { av[j] = av2[j]; pv[j] = pv2[j]; nv[j] = nv2[j]; }
+                for (int j = 0; j < EPL; ++j) {
+                    av[j] = a_new ? av2[j] : av[j];
+                    pv[j] = pn_new ? pv2[j] : pv[j];
+                    nv[j] = pn_new ? nv2[j] : nv[j];
+                }
             }
+        }
+    }
+    if (GRAD && qn > 0) {                                               // the ring's last (fewer than eight) rows
+        constexpr int RPI = 64 / E;
+#pragma unroll
+        for (int r = 0; r < EPL; ++r) {
+            const int t_ = r * RPI + lane / E, e = lane % E;
+            const int slot = (qh + t_) & 15;
+            if (t_ < qn) atomicAdd(gxn + (unsigned)(qid[slot] * E + e), qrows[slot * LD + e]);
         }
     }
     if (GRAD && cur >= 0) {
@@ -1463,7 +1514,7 @@ extern "C" int hpcs_hyphc_sampled(const float* xn, const int64_t* labels, const 
         if (grid.x % pm != 0) { perm_mul = pm; break; }
     const bool grad = gxn != nullptr;
     const int LD = E + 8;
-    const size_t slab_bytes = (size_t)(SB_THREADS / 64) * 8 * LD * sizeof(float);
+    const size_t slab_bytes = (size_t)(SB_THREADS / 64) * (16 * LD + 16) * sizeof(float);     // negative-row rings + ids
     // one 1024-thread workgroup per CU (forcing 8 waves/SIMD spills: measured 2.4x slower): 128 KB of LDS
     int RC = grad ? (int)((128 * 1024 - slab_bytes) / ((E + 8) * sizeof(float))) : 0;     // rows of the positive table
     if (RC > 1024) RC = 1024;
