@@ -197,8 +197,7 @@ __global__ __launch_bounds__(256) void gemm_tn_small_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// weight-grad: both operands have the reduction index (columns) contiguous.  LDS rows padded to BKC+1 so the
-// 32 lanes of an operand fetch (32 different rows, same column) hit 32 different banks.
+// weight-grad: both operands have the reduction index (columns) contiguous.
 template <int BM, int BN, int BKC, int WM, int WN>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(
     const float* __restrict__ G, int ldg, int64_t sGo, int64_t sGi, const float* __restrict__ X, int ldx,
@@ -206,10 +205,17 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(
     int nsplit, float* __restrict__ part, int tilesM, int tilesK, int vecG, int vecX) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int LD = BKC + 1;
+    // Row pitch BKC + 4 floats: rows start on 16 bytes, so staging is one ds_write_b128 per float4 and the MFMA operands
+    // are fetched with ds_read_b128 (four consecutive columns = two k-steps per lane); at a 144-byte pitch eight
+    // consecutive rows cover the eight 16-byte bank groups, so both are conflict-free.  (A BKC + 1 pitch with scalar
+    // LDS traffic made the EdgeConv shapes LDS-issue bound: 238 -> 178 us.)
+    // The 128x128 instantiation keeps the BKC + 1 pitch with scalar LDS traffic (odd pitch: the 32 rows of an operand
+    // fetch hit 32 banks): with 64 accumulator registers the vector form spills (measured 1.43 -> 2.29 ms).
+    constexpr bool V4 = BM == 64;
+    constexpr int LD = V4 ? BKC + 4 : BKC + 1;
     constexpr int G_LD = BM * BKC / 4 / NT, X_LD = BN * BKC / 4 / NT;
-    __shared__ float Gs[BM][LD];
-    __shared__ float Xs[BN][LD];
+    __shared__ __attribute__((aligned(16))) float Gs[BM][LD];
+    __shared__ __attribute__((aligned(16))) float Xs[BN][LD];
 
     const int tile = blockIdx.x % (tilesM * tilesK);
     const int split = blockIdx.x / (tilesM * tilesK);
@@ -266,12 +272,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(
 #pragma unroll
         for (int i = 0; i < G_LD; ++i) {
             const int f = tid + i * NT, row = f / (BKC / 4), c4 = (f % (BKC / 4)) * 4;
-            Gs[row][c4] = rg[i].x; Gs[row][c4 + 1] = rg[i].y; Gs[row][c4 + 2] = rg[i].z; Gs[row][c4 + 3] = rg[i].w;
+            if (V4) *reinterpret_cast<float4*>(&Gs[row][c4]) = rg[i];
+            else { Gs[row][c4] = rg[i].x; Gs[row][c4 + 1] = rg[i].y; Gs[row][c4 + 2] = rg[i].z; Gs[row][c4 + 3] = rg[i].w; }
         }
 #pragma unroll
         for (int i = 0; i < X_LD; ++i) {
             const int f = tid + i * NT, row = f / (BKC / 4), c4 = (f % (BKC / 4)) * 4;
-            Xs[row][c4] = rx[i].x; Xs[row][c4 + 1] = rx[i].y; Xs[row][c4 + 2] = rx[i].z; Xs[row][c4 + 3] = rx[i].w;
+            if (V4) *reinterpret_cast<float4*>(&Xs[row][c4]) = rx[i];
+            else { Xs[row][c4] = rx[i].x; Xs[row][c4 + 1] = rx[i].y; Xs[row][c4 + 2] = rx[i].z; Xs[row][c4 + 3] = rx[i].w; }
         }
         __syncthreads();
         // advance and prefetch
@@ -282,18 +290,35 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(
             if (have) unit_bounds(u, c0, c_end_u);
         }
         if (have) gload(u, c0);
+        if (!V4) {
 #pragma unroll
-        for (int kk = 0; kk < BKC / 2; ++kk) {
-            float a[TM], b[TN];
+            for (int kk = 0; kk < BKC / 2; ++kk) {
+                float a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = Gs[wm * (BM / WM) + i * 32 + lr][kk * 2 + lk];
+                for (int i = 0; i < TM; ++i) a[i] = Gs[wm * (BM / WM) + i * 32 + lr][kk * 2 + lk];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Xs[wn * (BN / WN) + j * 32 + lr][kk * 2 + lk];
+                for (int j = 0; j < TN; ++j) b[j] = Xs[wn * (BN / WN) + j * 32 + lr][kk * 2 + lk];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        } else
+#pragma unroll
+        for (int k4 = 0; k4 < BKC / 4; ++k4) {               // columns 4*k4 .. 4*k4+3 = k-steps 2*k4 and 2*k4+1
+            float4 a4[TM], b4[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a4[i] = *reinterpret_cast<const float4*>(&Gs[wm * (BM / WM) + i * 32 + lr][k4 * 4]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b4[j] = *reinterpret_cast<const float4*>(&Xs[wn * (BN / WN) + j * 32 + lr][k4 * 4]);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(lk ? a4[i].y : a4[i].x, lk ? b4[j].y : b4[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(lk ? a4[i].w : a4[i].z, lk ? b4[j].w : b4[j].z, acc[i][j], 0, 0, 0);
+                }
         }
     }
     float* P = part + (int64_t)split * M * Kx;
@@ -308,6 +333,117 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(
                 if (row < M && col < Kx) P[(int64_t)row * Kx + col] = acc[i][j][r];
             }
         }
+}
+
+// EdgeConv weight gradients: one output tile with M, Kx <= 48 over millions of columns.  On the 64x64 tile of the
+// kernel above the 42x42 result uses 43 % of every 32x32x2 MFMA; here the tile is 3x3 blocks of v_mfma_f32_16x16x4_f32
+// (48x48: 77 %), the four waves split each 32-column step (eight columns = two k4-steps each, all nine blocks) and
+// add their accumulators through LDS at the end.  Same split plan and partials as the general kernel.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int NE_T = 48;
+__global__ __launch_bounds__(256) void gemm_nt_edge_kernel(
+    const float* __restrict__ G, int ldg, int64_t sGo, int64_t sGi, const float* __restrict__ X, int ldx,
+    int64_t sXo, int64_t sXi, int M, int Kx, int Nc, int n_inner, int n_batch, int chunk, int units_per_batch,
+    int nsplit, float* __restrict__ part, int vecG, int vecX) {
+    constexpr int BKC = 32, NT = 256, LD = BKC + 4;          // pitch 36: 16-byte row starts (ds_write_b128), operand fetch
+                                                             // (16 rows x 4 columns per instruction) spreads over all banks
+    constexpr int NLD = NE_T * (BKC / 4);                    // 384 float4 per operand tile
+    __shared__ __attribute__((aligned(16))) float sm[2][NE_T][LD];      // Gs, Xs; reused for the final 48x48 reduction
+    float (*Gs)[LD] = sm[0];
+    float (*Xs)[LD] = sm[1];
+    const int split = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+
+    f32x4 acc[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+    const int64_t units = (int64_t)n_batch * units_per_batch;
+    float4 rg[2], rx[2];
+    auto gload = [&](int64_t u, int c0) {
+        const int batch = (int)(u / units_per_batch);
+        const int c_begin = (int)(u % units_per_batch) * chunk;
+        const int c_end = min(Nc, c_begin + chunk);
+        const int bo = batch / n_inner, bi = batch % n_inner;
+        const float* Gp = G + bo * sGo + bi * sGi;
+        const float* Xp = X + bo * sXo + bi * sXi;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = tid + i * NT, row = f / (BKC / 4), c4 = (f % (BKC / 4)) * 4;
+            const bool in = f < NLD;
+            rg[i] = ld4_guard(Gp + (int64_t)row * ldg, c0 + c4, c_end, in && row < M, vecG);
+            rx[i] = ld4_guard(Xp + (int64_t)row * ldx, c0 + c4, c_end, in && row < Kx, vecX);
+        }
+    };
+    int64_t u = split;
+    int c0 = 0, c_end_u = 0;
+    auto unit_bounds = [&](int64_t uu, int& cb, int& ce) {
+        cb = (int)(uu % units_per_batch) * chunk;
+        ce = min(Nc, cb + chunk);
+    };
+    bool have = u < units;
+    if (have) {
+        unit_bounds(u, c0, c_end_u);
+        gload(u, c0);
+    }
+    while (have) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = tid + i * NT, row = f / (BKC / 4), c4 = (f % (BKC / 4)) * 4;
+            if (f < NLD) {
+                *reinterpret_cast<float4*>(&Gs[row][c4]) = rg[i];
+                *reinterpret_cast<float4*>(&Xs[row][c4]) = rx[i];
+            }
+        }
+        __syncthreads();
+        c0 += BKC;
+        if (c0 >= c_end_u) {
+            u += nsplit;
+            have = u < units;
+            if (have) unit_bounds(u, c0, c_end_u);
+        }
+        if (have) gload(u, c0);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int col = 4 * (2 * w + q) + lq;            // this lane's column of the k4-step
+            float a[3], b[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                a[i] = Gs[i * 16 + li][col];
+                b[i] = Xs[i * 16 + li][col];
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // add the four waves' accumulators in wave order through LDS, then store this split's partial
+    float* tile = &sm[0][0][0];                              // 48 x 48 floats fit in the two staging tiles
+    for (int ww = 0; ww < 4; ++ww) {
+        __syncthreads();
+        if (w == ww) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float* t = tile + (i * 16 + 4 * lq + r) * NE_T + j * 16 + li;
+                        *t = ww == 0 ? acc[i][j][r] : *t + acc[i][j][r];
+                    }
+        }
+    }
+    __syncthreads();
+    float* P = part + (int64_t)split * M * Kx;
+    for (int e = tid; e < M * Kx; e += NT) P[e] = tile[(e / Kx) * NE_T + e % Kx];
 }
 
 // Sums the split partials in a FIXED order (deterministic).  64 outputs per workgroup, 16 waves each own every
@@ -460,7 +596,11 @@ extern "C" int hpcs_gemm_nt(const float* G, int ldg, int64_t strideG_o, int64_t 
     const int vecG = (ldg % 4 == 0) && (strideG_o % 4 == 0) && (strideG_i % 4 == 0) && aligned16(G);
     const int vecX = (ldx % 4 == 0) && (strideX_o % 4 == 0) && (strideX_i % 4 == 0) && aligned16(X);
     const long blocks = (long)p.tilesM * p.tilesK * p.nsplit;
-    if (p.tile == 128)
+    if (p.tilesM * p.tilesK == 1 && M <= NE_T && Kx <= NE_T && !getenv("HPCS_NT_NO_EDGE"))
+        hipLaunchKernelGGL(gemm_nt_edge_kernel, dim3((unsigned)blocks), dim3(256), 0, st, G, ldg, strideG_o, strideG_i, X, ldx,
+                           strideX_o, strideX_i, M, Kx, Nc, n_inner, nb, p.chunk, p.units_per_batch, p.nsplit, (float*)ws, vecG,
+                           vecX);
+    else if (p.tile == 128)
         hipLaunchKernelGGL((gemm_nt_kernel<128, 128, NT_BKC, 2, 2>), dim3((unsigned)blocks), dim3(256), 0, st, G, ldg,
                            strideG_o, strideG_i, X, ldx, strideX_o, strideX_i, M, Kx, Nc, n_inner, nb, p.chunk,
                            p.units_per_batch, p.nsplit, (float*)ws, p.tilesM, p.tilesK, vecG, vecX);
