@@ -596,7 +596,7 @@ extern "C" int hpcs_gemm_nt(const float* G, int ldg, int64_t strideG_o, int64_t 
     const int vecG = (ldg % 4 == 0) && (strideG_o % 4 == 0) && (strideG_i % 4 == 0) && aligned16(G);
     const int vecX = (ldx % 4 == 0) && (strideX_o % 4 == 0) && (strideX_i % 4 == 0) && aligned16(X);
     const long blocks = (long)p.tilesM * p.tilesK * p.nsplit;
-    if (p.tilesM * p.tilesK == 1 && M <= NE_T && Kx <= NE_T && !getenv("HPCS_NT_NO_EDGE"))
+    if (p.tilesM * p.tilesK == 1 && M <= NE_T && Kx <= NE_T)
         hipLaunchKernelGGL(gemm_nt_edge_kernel, dim3((unsigned)blocks), dim3(256), 0, st, G, ldg, strideG_o, strideG_i, X, ldx,
                            strideX_o, strideX_i, M, Kx, Nc, n_inner, nb, p.chunk, p.units_per_batch, p.nsplit, (float*)ws, vecG,
                            vecX);
