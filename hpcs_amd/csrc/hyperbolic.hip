@@ -232,6 +232,50 @@ __global__ void hyperbolic_sim_mat_kernel(const float* __restrict__ x, const flo
     out[(int64_t)i * Mp + j] = expf(-acoshf(dxy));
 }
 
+// HyperbolicLCA (hpcs/distances/poincare.py:190-237), E = 2 read as complex numbers.  For a pair (x, y) of projected
+// points: w = M_x(y) = (y - x) / (1 - conj(x) y) sends x to the origin; the geodesic midpoint is mid = tanh(artanh|w| / 2)
+// w / |w|; m = M_x^{-1}(mid) = (mid + x) / (1 + conj(x) mid); result = min(d(o,x), d(o,y), d(o,m)), d(o,p) = 2 artanh|p|
+// with the reference's fp32 input clamp.  pairs != 0: row-aligned pairs (out [M]); else the full [M, Mp] matrix.
+__device__ __forceinline__ void project2(const float* __restrict__ p, float& re, float& im) {
+    const float a = p[0], b = p[1];
+    const float n = fmaxf(sqrtf(a * a + b * b), MIN_NORM);
+    const float maxn = 1.f - BALL_EPS_F32;
+    const float sc = n > maxn ? maxn / n : 1.f;
+    re = a * sc;
+    im = b * sc;
+}
+__device__ __forceinline__ float lca_pair(float xr, float xi, float yr, float yi) {
+    const float dox = (float)(2.0 * artanh_clamped((double)sqrtf(xr * xr + xi * xi), nullptr));
+    const float doy = (float)(2.0 * artanh_clamped((double)sqrtf(yr * yr + yi * yi), nullptr));
+    // w = (y - x) / (1 - conj(x) y)
+    const float nr = yr - xr, ni = yi - xi;
+    const float dr = 1.f - (xr * yr + xi * yi), di = -(xr * yi - xi * yr);
+    const float dd = dr * dr + di * di;
+    const float wr = (nr * dr + ni * di) / dd, wi = (ni * dr - nr * di) / dd;
+    // midpoint with the origin: mobius_mul(w, 0.5)
+    const float wn = fmaxf(sqrtf(wr * wr + wi * wi), MIN_NORM);
+    const float half = (float)(0.5 * artanh_clamped((double)wn, nullptr));
+    const float t = tanhf(fminf(fmaxf(half, -15.f), 15.f)) / wn;
+    const float mr = t * wr, mi = t * wi;
+    // m = (mid + x) / (1 + conj(x) mid)
+    const float pr = mr + xr, pi = mi + xi;
+    const float qr = 1.f + (xr * mr + xi * mi), qi = xr * mi - xi * mr;
+    const float qq = qr * qr + qi * qi;
+    const float zr = (pr * qr + pi * qi) / qq, zi = (pi * qr - pr * qi) / qq;
+    const float dom = (float)(2.0 * artanh_clamped((double)sqrtf(zr * zr + zi * zi), nullptr));
+    return fminf(fminf(dox, doy), dom);
+}
+__global__ void hyperbolic_lca_kernel(const float* __restrict__ x, const float* __restrict__ y, int M, int Mp, int pairs,
+                                      float* __restrict__ out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = pairs ? j : blockIdx.y;
+    if (j >= (pairs ? M : Mp)) return;
+    float xr, xi, yr, yi;
+    project2(x + 2 * (int64_t)i, xr, xi);
+    project2(y + 2 * (int64_t)j, yr, yi);
+    out[pairs ? (int64_t)j : (int64_t)i * Mp + j] = lca_pair(xr, xi, yr, yi);
+}
+
 __global__ void cosine_mat_kernel(const float* __restrict__ xn, const float* __restrict__ yn, int M, int Mp, int E,
                                   float* __restrict__ out) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -386,6 +430,19 @@ extern "C" int hpcs_hyperbolic_sim_mat(const float* x, const float* y, int M, in
     if (M < 0 || Mp < 0 || E <= 0 || M > 65535) return HPCS_ERR_SHAPE;
     if (M == 0 || Mp == 0) return HPCS_OK;
     hipLaunchKernelGGL(hyperbolic_sim_mat_kernel, dim3(hpcs_cdiv(Mp, 256), M), dim3(256), 0, ST, x, y, M, Mp, E, out);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+extern "C" int hpcs_hyperbolic_lca(const float* x, const float* y, int M, int Mp, int E, int pairs, float* out,
+                                   hpcs_stream_t stream) {
+    if (!x || !y || !out) return HPCS_ERR_NULL;
+    if (M < 0 || Mp < 0 || M > 65535 || (pairs && M != Mp)) return HPCS_ERR_SHAPE;
+    if (E != 2) return HPCS_ERR_UNSUPPORTED;               // the reference views the points as complex numbers
+    if (M == 0 || Mp == 0) return HPCS_OK;
+    if (pairs)
+        hipLaunchKernelGGL(hyperbolic_lca_kernel, dim3(hpcs_cdiv(M, 256), 1), dim3(256), 0, ST, x, y, M, Mp, 1, out);
+    else
+        hipLaunchKernelGGL(hyperbolic_lca_kernel, dim3(hpcs_cdiv(Mp, 256), M), dim3(256), 0, ST, x, y, M, Mp, 0, out);
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;
 }

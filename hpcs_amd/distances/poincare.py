@@ -70,3 +70,38 @@ class HyperbolicDistance:
         xx = 1 - torch.norm(x, dim=-1, p=2) ** 2
         yy = 1 - torch.norm(y, dim=-1, p=2) ** 2
         return torch.exp(-torch.acosh(1 + 2 * (xy / (xx * yy))))
+
+
+class HyperbolicLCA:
+    """min(d(o,x), d(o,y), d(o, midpoint of the geodesic x-y)) on projected points of the Poincare DISC (E = 2; the
+    reference works on torch.view_as_complex) -- hpcs/distances/poincare.py:190-237.  Never instantiated by the
+    reference's callers; part of the hpcs.distances API surface."""
+    is_inverted = False
+    normalize_embeddings = False
+    p = 2
+
+    def __call__(self, query_emb, ref_emb=None):
+        return self.compute_mat(query_emb, ref_emb)
+
+    @staticmethod
+    def _check(t):
+        if t.dim() != 2 or t.shape[-1] != 2:
+            raise RuntimeError("HyperbolicLCA works on [N, 2] embeddings (view_as_complex needs a last dimension of 2)")
+        return t.detach().contiguous().float()
+
+    def compute_mat(self, query_emb, ref_emb=None):
+        x = self._check(query_emb)
+        y = x if ref_emb is None else self._check(ref_emb)
+        out = torch.empty(x.shape[0], y.shape[0], device=x.device, dtype=torch.float32)
+        _lib.call("hpcs_hyperbolic_lca", x, y, x.shape[0], y.shape[0], 2, 0, out)
+        return out
+
+    def pairwise_distance(self, query_emb, ref_emb):
+        """Row-aligned pairs -> [N, 1] like the reference's hyp_dist_o-shaped result.  (The reference's own code takes the
+        first minimum with Python's builtin min(), so it only runs for N = 1; this is the element-wise reading.)"""
+        x, y = self._check(query_emb), self._check(ref_emb)
+        if x.shape[0] != y.shape[0]:
+            raise RuntimeError("pairwise_distance needs the same number of rows")
+        out = torch.empty(x.shape[0], device=x.device, dtype=torch.float32)
+        _lib.call("hpcs_hyperbolic_lca", x, y, x.shape[0], y.shape[0], 2, 1, out)
+        return out.unsqueeze(-1)

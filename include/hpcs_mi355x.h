@@ -202,6 +202,10 @@ int hpcs_hyp_lca_bwd(const float* a, const float* b, const float* gdist, int64_t
                      hpcs_stream_t stream);
 /* a15: HyperbolicDistance.compute_mat  hpcs/distances/poincare.py:144-176 -> sim [M,M'] */
 int hpcs_hyperbolic_sim_mat(const float* x, const float* y, int M, int Mp, int E, float* out, hpcs_stream_t stream);
+/* HyperbolicLCA.compute_mat / pairwise_distance  hpcs/distances/poincare.py:190-237 (E == 2 only: the reference reads the
+ * points as complex numbers): min(d(o,x), d(o,y), d(o, midpoint of the geodesic x-y)) on projected points.
+ * pairs == 0: out [M, Mp]; pairs != 0 (M == Mp): row-aligned pairs, out [M]. */
+int hpcs_hyperbolic_lca(const float* x, const float* y, int M, int Mp, int E, int pairs, float* out, hpcs_stream_t stream);
 
 /* ---- a8-a14: miner and losses -----------------------------------------------------------------
  * All matrix-free: the (B*N)^2 cosine matrix of hpcs/loss/ultrametric_loss.py:65 is never built.

@@ -178,3 +178,38 @@ def hyperbolic_similarity_pairs(x, y):
     ax = 1 - torch.norm(x, dim=-1, p=2) ** 2
     ay = 1 - torch.norm(y, dim=-1, p=2) ** 2
     return torch.exp(-torch.acosh(1 + 2 * (d2 / (ax * ay))))
+
+
+def _complex_mobius_to_origin(z, x):
+    """mobius_transf (hpcs/distances/poincare.py:81-96), E = 2 read as complex numbers: the disc isometry that sends z to 0,
+    applied to x: (x - z) / (1 - conj(z) x).  z [N,2], x [M,2] -> [N,M,2]."""
+    z1 = torch.view_as_complex(z.contiguous()).view(-1, 1)
+    x1 = torch.view_as_complex(x.contiguous()).view(1, -1)
+    return torch.view_as_real((x1 - z1) / (1 - z1.conj() * x1))
+
+
+def _complex_mobius_from_origin(z, w):
+    """inverse_mobius_transf (poincare.py:99-115): (w + z) / (1 + conj(z) w) with w [N,M,2] already paired with z [N,2]."""
+    z1 = torch.view_as_complex(z.contiguous()).view(-1, 1)
+    w1 = torch.view_as_complex(w.contiguous())
+    return torch.view_as_real((w1 + z1) / (1 + z1.conj() * w1))
+
+
+def hyperbolic_lca_mat(x, y=None):
+    """HyperbolicLCA.compute_mat (poincare.py:197-222), E = 2: for every pair the smallest of d(o,x), d(o,y), d(o,m),
+    m = hyperbolic midpoint of the geodesic x-y (map x to the origin, halve M(y) there, map back)."""
+    y = x if y is None else y
+    x = project(x)
+    y = project(y)
+    dox = hyp_dist_o(x)                                   # [N,1]
+    doy = hyp_dist_o(y).T                                 # [1,M]
+    mid = midpoint_o(_complex_mobius_to_origin(x, y))     # [N,M,2]
+    dom = hyp_dist_o(_complex_mobius_from_origin(x, mid))[..., 0]
+    return torch.min(torch.min(dox + torch.zeros_like(dom), doy + torch.zeros_like(dom)), dom)
+
+
+def hyperbolic_lca_pairs(x, y):
+    """HyperbolicLCA.pairwise_distance (poincare.py:225-237) for row-aligned x, y [N,2] -> [N].  (The reference takes the
+    first minimum with Python's builtin min(), which only runs for N = 1; this is the element-wise reading.)"""
+    full = hyperbolic_lca_mat(x, y)
+    return torch.diagonal(full)

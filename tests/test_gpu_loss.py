@@ -287,3 +287,29 @@ def test_class_index_is_stable_grouping(M, C):
     want_off = torch.cat([torch.zeros(1, dtype=torch.int64), torch.bincount(lab, minlength=C).cumsum(0)]).to(torch.int32)
     assert torch.equal(offsets.cpu(), want_off)
     assert torch.equal(order.cpu(), want_order)
+
+
+def test_hyperbolic_lca_matches_reference_fixture():
+    """a15: hpcs_amd.distances.poincare.HyperbolicLCA against the reference's outputs (tests/golden/hyperbolic_lca.npz) and
+    the oracle; E != 2 is refused like torch.view_as_complex refuses it."""
+    import os
+    from hpcs_amd.distances.poincare import HyperbolicLCA
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hyperbolic_lca.npz"))
+    x, y = torch.as_tensor(g["x"]), torch.as_tensor(g["y"])
+    lca = HyperbolicLCA()
+    got = lca.compute_mat(x.to(dev), y.to(dev)).cpu()
+    assert float((got - torch.as_tensor(g["mat_xy"])).abs().max()) <= 2e-5
+    got = lca(x.to(dev)).cpu()
+    assert float((got - torch.as_tensor(g["mat_xx"])).abs().max()) <= 2e-5
+    got = lca.pairwise_distance(x[:23].to(dev), y.to(dev)).cpu()
+    assert got.shape == (23, 1)
+    assert float((got[:, 0] - torch.as_tensor(g["pairs"])).abs().max()) <= 2e-5
+    # random disc points incl. near-boundary pairs, where 1 - conj(x) y cancels in fp32: the yardstick is the oracle in
+    # fp64, and the HIP result may not be further from it than a few times the reference's own fp32 evaluation is
+    big = det_normalish((300, 2), 8200) * 0.6
+    ref64 = OH.hyperbolic_lca_mat(OH.project(big).double())
+    err_hip = float((lca(big.to(dev)).cpu().double() - ref64).abs().max())
+    err_ref32 = float((OH.hyperbolic_lca_mat(big).double() - ref64).abs().max())
+    assert err_hip <= max(5e-5, 3.0 * err_ref32), (err_hip, err_ref32)
+    with pytest.raises(RuntimeError):
+        lca(torch.zeros(4, 3, device=dev))

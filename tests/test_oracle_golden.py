@@ -286,3 +286,16 @@ def test_radam(golden):
     for i in range(len(ps)):
         close(states[i]["exp_avg"], golden[f"radam_final_m{i}"], rtol=1e-5, atol=1e-7)
         close(states[i]["exp_avg_sq"], golden[f"radam_final_v{i}"], rtol=1e-5, atol=1e-9)
+
+
+def test_hyperbolic_lca_oracle_matches_reference():
+    """a15: HyperbolicLCA (never instantiated by the reference's callers; API surface).  Fixture: tests/golden/
+    hyperbolic_lca.npz, produced by tests/golden/make_golden_lca.py from the reference's own class."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hyperbolic_lca.npz"))
+    x, y = torch.as_tensor(g["x"]), torch.as_tensor(g["y"])
+    assert float((OH.hyperbolic_lca_mat(x, y) - torch.as_tensor(g["mat_xy"])).abs().max()) <= 1e-6
+    assert float((OH.hyperbolic_lca_mat(x) - torch.as_tensor(g["mat_xx"])).abs().max()) <= 1e-6
+    assert float((OH.hyperbolic_lca_pairs(x[:23], y) - torch.as_tensor(g["pairs"])).abs().max()) <= 1e-6
+    m = OH.hyperbolic_lca_mat(x, y)
+    assert float(m.min()) >= 0.0 and float(m[0].abs().max()) == 0.0        # LCA with the origin is the origin
