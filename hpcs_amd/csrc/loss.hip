@@ -1210,6 +1210,53 @@ __global__ __launch_bounds__(256) void cosface_bwd_tile_kernel(const float* __re
     }
 }
 
+// ---- in-step metrics (next row f3): what base_hyp_hc.py:88-99,126-130 hands to torchmetrics every training step -------
+// softmax is monotone, so the predicted class is the arg-max logit (first maximum on ties, like torch.argmax).  One
+// thread per row; per-workgroup LDS counters [3][C] = {true positives, predictions, targets} per class, flushed with
+// one integer atomic per touched counter.
+__global__ __launch_bounds__(256) void class_metrics_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                           int M, int C, unsigned long long* __restrict__ counts) {
+    extern __shared__ unsigned int cm[];              // [3][C]
+    for (int i = threadIdx.x; i < 3 * C; i += 256) cm[i] = 0u;
+    __syncthreads();
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row < M) {
+        const float* lr = logits + (int64_t)row * C;
+        float bv = lr[0];
+        int bc = 0;
+        for (int c = 1; c < C; ++c) {
+            const float v = lr[c];
+            if (v > bv) { bv = v; bc = c; }
+        }
+        const int64_t y = labels[row];
+        atomicAdd(&cm[C + bc], 1u);
+        if (y >= 0 && y < C) {
+            atomicAdd(&cm[2 * C + (int)y], 1u);
+            if ((int)y == bc) atomicAdd(&cm[bc], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * C; i += 256)
+        if (cm[i]) atomicAdd(counts + i, (unsigned long long)cm[i]);
+}
+// acc = sum TP / M (micro, top-1); iou = mean over the classes present in predictions or targets of TP / (P + T - TP)
+__global__ void class_metrics_finalize_kernel(const unsigned long long* __restrict__ counts, int M, int C,
+                                              float* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double tp = 0.0, iou = 0.0;
+    int present = 0;
+    for (int c = 0; c < C; ++c) {
+        const double t = (double)counts[c], p = (double)counts[C + c], y = (double)counts[2 * C + c];
+        tp += t;
+        if (p + y > 0.0) {
+            ++present;
+            iou += t / (p + y - t);
+        }
+    }
+    out[0] = M > 0 ? (float)(tp / (double)M) : 0.f;
+    out[1] = present > 0 ? (float)(iou / (double)present) : 0.f;
+}
+
 __device__ __forceinline__ void triplet_sims(const float* __restrict__ xn, int E, int64_t ia, int64_t ip, int64_t in, int s,
                                              float& wij, float& wik, float& wjk) {
     float d1 = 0.f, d2 = 0.f, d3 = 0.f;
@@ -1439,6 +1486,22 @@ extern "C" int hpcs_cosface_bwd(const float* xn, const float* wn, const int64_t*
     if (rpb < 1) return HPCS_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(cosface_bwd_w_kernel, dim3(hpcs_cdiv(M, rpb)), dim3(TPB), (size_t)rpb * C * 4, ST, xn, labels, logits,
                        lse_rows, branch_id, n_levels, M, E, C, scale, gloss, rpb, gwn);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
+extern "C" int hpcs_class_metrics(const float* logits, const int64_t* labels, int M, int C, int64_t* counts, float* acc_iou,
+                                  hpcs_stream_t stream) {
+    if (!logits || !labels || !counts || !acc_iou) return HPCS_ERR_NULL;
+    if (M < 0 || C <= 0 || C > 4096) return HPCS_ERR_SHAPE;
+    if (hipMemsetAsync(counts, 0, sizeof(int64_t) * 3 * C, ST) != hipSuccess) return HPCS_ERR_HIP;
+    if (M > 0) {
+        hipLaunchKernelGGL(class_metrics_kernel, dim3(hpcs_cdiv(M, 256)), dim3(256), sizeof(unsigned) * 3 * C, ST, logits, labels,
+                           M, C, (unsigned long long*)counts);
+        HPCS_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(class_metrics_finalize_kernel, dim3(1), dim3(64), 0, ST, (const unsigned long long*)counts, M, C,
+                       acc_iou);
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;
 }

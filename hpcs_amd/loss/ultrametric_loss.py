@@ -194,7 +194,20 @@ class CosFaceLoss(torch.nn.Module):
                                float(self.scale), bid)
 
     def forward(self, embeddings, labels, xn=None):
-        return self.logits_and_loss(embeddings, labels, xn)[0]
+        loss, logits = self.logits_and_loss(embeddings, labels, xn)
+        self.last_logits = logits               # margin-adjusted, scaled: what get_logits() returns (in-step metrics)
+        return loss
+
+
+def class_metrics(logits, labels):
+    """(accuracy, IoU) device scalars from [M,C] logits and int labels: base_hyp_hc.py:88-99 without torchmetrics
+    (micro top-1 accuracy; macro Jaccard over the classes present in predictions or targets)."""
+    logits = logits.detach().contiguous().float()
+    M, C = logits.shape
+    counts = torch.empty(3 * C, dtype=torch.int64, device=logits.device)
+    out = torch.empty(2, dtype=torch.float32, device=logits.device)
+    call("hpcs_class_metrics", logits, labels.reshape(-1).to(torch.int64).contiguous(), M, C, counts, out)
+    return out[0], out[1]
 
 
 class HierarchicalCosFaceLoss(CosFaceLoss):

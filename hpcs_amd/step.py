@@ -69,6 +69,7 @@ class HypHCStep(torch.nn.Module):
         self._rot_seed = int(torch.initial_seed()) & (2 ** 62 - 1)
         self._rot_calls = 0
         self.side_stream_wgrad = True
+        self.metrics = True
         self.optimizer = None
         self.bucket = None
 
@@ -93,8 +94,15 @@ class HypHCStep(torch.nn.Module):
         xp = x_poincare.contiguous().view(-1, x_poincare.shape[-1])
         y = targets.reshape(-1).long()
         loss = self.metric_hyp_loss.compute_loss(xe, xp, y, plan=plan)
-        return {"loss_metric": loss["loss_metric"]["losses"],
-                "loss_hyp": loss["loss_hyp"]["losses"] * self.trade_off}
+        out = {"loss_metric": loss["loss_metric"]["losses"],
+               "loss_hyp": loss["loss_hyp"]["losses"] * self.trade_off}
+        if self.metrics and hasattr(self.metric_hyp_loss, "loss_cosface"):
+            # base_hyp_hc.py:126-130: accuracy / IoU of the CosFace logits every step (device scalars, no sync); the
+            # logits are the ones the loss kernel just produced
+            from .loss.ultrametric_loss import class_metrics
+            acc, iou = class_metrics(self.metric_hyp_loss.loss_cosface.last_logits, y)
+            out["acc"], out["iou"] = acc, iou
+        return out
 
     def training_step(self, points, label, targets, targets_host=None, rot=None, drop_masks=None):
         """One optimisation step.  targets_host (CPU copy of the part labels) lets the miner's per-class plan be

@@ -280,6 +280,14 @@ int hpcs_cosface_fwd(const float* xn, const float* wn, const int64_t* labels, co
 int hpcs_cosface_bwd(const float* xn, const float* wn, const int64_t* labels, const float* logits,
                      const float* lse_rows, const int32_t* branch_id, int n_levels, int M, int E, int C, float scale,
                      const float* gloss, float* gxn, float* gwn, hpcs_stream_t stream);
+/* ---- next row f3: in-step metrics  hpcs/models/base_hyp_hc.py:88-99,126-130 -----------------------------------------
+ * The reference feeds softmax(get_logits(...)) to torchmetrics (pinned 0.10.1 in hpcs-env.yaml, but the constructor calls
+ * need >= 0.11: Accuracy(task='multiclass', top_k=1) = micro accuracy; MulticlassJaccardIndex = macro IoU over the
+ * classes that occur in predictions or targets).  torchmetrics is a third-party dependency absent from this image:
+ * its published algorithm is restated (parity unpinned).  logits [M,C] = hpcs_cosface_fwd's; counts [3*C] int64
+ * (true positives, predictions, targets per class) overwritten; acc_iou [2] = {accuracy, IoU}. */
+int hpcs_class_metrics(const float* logits, const int64_t* labels, int M, int C, int64_t* counts, float* acc_iou,
+                       hpcs_stream_t stream);
 int hpcs_triplet_margin_fwd(const float* xn, int E, const int64_t* a, const int64_t* p, const int64_t* n,
                             const int64_t* count, int64_t T_cap, float margin, double* sum_and_nnz,
                             hpcs_stream_t stream);

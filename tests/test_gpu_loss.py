@@ -313,3 +313,24 @@ def test_hyperbolic_lca_matches_reference_fixture():
     assert err_hip <= max(5e-5, 3.0 * err_ref32), (err_hip, err_ref32)
     with pytest.raises(RuntimeError):
         lca(torch.zeros(4, 3, device=dev))
+
+
+@pytest.mark.parametrize("M,C", [(5000, 50), (257, 4), (64, 600)])
+def test_class_metrics_match_confusion_matrix(M, C):
+    """hpcs_class_metrics: micro top-1 accuracy and macro IoU over the classes present in predictions or targets
+    (torchmetrics' Accuracy(task='multiclass') / MulticlassJaccardIndex as the reference uses them, restated)."""
+    from hpcs_amd.loss.ultrametric_loss import class_metrics
+    logits = det_normalish((M, C), 9100 + C)
+    logits[:7] = 0.25                                  # ties: the first maximum wins (torch.argmax)
+    y = det_int((M,), 9101, max(1, C - 1))             # the last class never occurs as a target
+    acc, iou = class_metrics(logits.to(dev), y.to(dev))
+    pred = logits.argmax(dim=1)
+    assert int(pred[:7].max()) == 0
+    conf = torch.zeros(C, C, dtype=torch.float64)
+    conf.index_put_((y, pred), torch.ones(M, dtype=torch.float64), accumulate=True)
+    tp = conf.diag()
+    denom = conf.sum(0) + conf.sum(1) - tp
+    present = (conf.sum(0) + conf.sum(1)) > 0
+    want_iou = float((tp[present] / denom[present]).mean())
+    want_acc = float(tp.sum() / M)
+    assert abs(float(acc) - want_acc) < 1e-6 and abs(float(iou) - want_iou) < 1e-6
