@@ -1,5 +1,6 @@
 """GPU property tests at BASELINE.json's full sizes (where the CPU oracle would take minutes):
 size-independent properties of the kNN, the extractor, the loss and the optimizer."""
+import numpy as np
 import pytest
 import torch
 
@@ -155,3 +156,25 @@ def test_so3_rotate_kernel_matches_torch_and_is_haar_like():
     Rm = rotate_to_channels_first(torch.zeros(4096, 1, 3, device=dev), seed=3, return_rot=True)[1]
     assert float(Rm.mean(0).abs().max()) < 0.05                                 # Haar: E[R] = 0
     assert abs(float(torch.diagonal(Rm, dim1=1, dim2=2).sum(1).var()) - 1.0) < 0.1    # Var(trace R) = 1 on SO(3)
+
+
+def test_training_reduces_the_loss_on_a_fixed_batch():
+    """End-to-end sanity of the whole step (extractor, losses, gradients on two streams, RAdam): 80 steps on one fixed
+    synthetic batch lower the total loss and the in-step metrics are finite numbers in [0, 1]."""
+    import argparse
+    import bench
+    args = argparse.Namespace(batch=4, points=256, k=10, embedding=32, num_class=6, num_categories=16, hierarchical=False)
+    torch.manual_seed(0)
+    step = bench.build_step(args, torch.device(dev))
+    for g in step.optimizer.param_groups:
+        g["lr"] = 0.005
+    pts, cat, tgt = bench.synthetic_batch(4, 256, 6, 16, seed=0)
+    pts_d, cat_d, tgt_d = pts.to(dev), cat.to(dev), tgt.to(dev)
+    hist = []
+    for i in range(81):
+        out = step.training_step(pts_d, cat_d, tgt_d, targets_host=tgt)
+        if i % 20 == 0:
+            hist.append({k_: float(v) for k_, v in out.items()})
+    assert all(np.isfinite(list(h.values())).all() for h in hist)
+    assert hist[-1]["total_loss"] < hist[0]["total_loss"] - 0.1, hist
+    assert all(0.0 <= h["acc"] <= 1.0 and 0.0 <= h["iou"] <= 1.0 for h in hist)
