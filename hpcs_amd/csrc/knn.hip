@@ -7,7 +7,9 @@
 //   score  = ((-sq_j) - (-2*gram)) - sq_i ;  order = (score desc, index asc)
 // This file is compiled with -ffp-contract=off so only the explicit fmaf's fuse.
 //
-// Two kernels:
+// Kernels (selection rule and measurements in launch_knn_mfma): knn_mfma_sort_kernel (k <= 32: the default), knn_mfma_queue_kernel
+// (k > 32), knn_mfma_kernel (per-score insertion: kept as the cross-check), knn_kernel (any D / no workspace).  All use the
+// same bit-defined arithmetic below.  The two original kernels:
 //  * knn_mfma_kernel (D = 3 and D = 63, k <= 40: the HPCS shapes).  One workgroup = one cloud x 32 queries, 4 waves.
 //    The Gram tile (32 candidates x 32 queries) is produced by v_mfma_f32_32x32x2_f32 with the candidates as the A
 //    operand (fetched straight from the [D,N] slab: lanes 0-31 read 128 contiguous bytes of row d, lanes 32-63 of
@@ -241,6 +243,133 @@ __global__ __launch_bounds__(MW * 64) void knn_mfma_kernel(const float* __restri
     }
 }
 
+// Sorting-network variant of the 4-wave kernel (k <= 32).  With eight short lists per query nearly every score enters some
+// list, so the per-score sorted insertion (~120 instructions) runs 16 times per tile.  Here a (score, index) pair is ONE
+// 64-bit key (order-preserving image of the float in the high word, ~index in the low word: larger key = better, ties
+// to the smaller index), the tile's 16 keys are sorted by a bitonic network (80 compare-exchanges of 5 instructions) and
+// merged with the sorted list by the classic max(A[i], B[31-i]) + bitonic-merge step (16 + 80 compare-exchanges).
+__device__ __forceinline__ unsigned long long knn_key(float s, int j) {
+    const unsigned u = __float_as_uint(s + 0.0f);                      // -0 -> +0: equal scores must give equal high words
+    const unsigned hi = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((unsigned long long)hi << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)j);
+}
+#define KNN_CE(a, b)                                                   \
+    {                                                                  \
+        const unsigned long long x_ = (a), y_ = (b);                   \
+        const bool sw_ = y_ > x_;                                      \
+        (a) = sw_ ? y_ : x_;                                           \
+        (b) = sw_ ? x_ : y_;                                           \
+    }
+
+template <int KSTEPS, int KK>
+__global__ __launch_bounds__(MW * 64) void knn_mfma_sort_kernel(const float* __restrict__ x, const float* __restrict__ sq, int D,
+                                                                int N, int k, int64_t* __restrict__ idx) {
+    static_assert(KK <= 32, "the merge network is 32 wide");
+    __shared__ unsigned long long lkey[MQ][2 * MW][KK];
+    const int tiles_q = (N + MQ - 1) / MQ;
+    const int b = blockIdx.x / tiles_q;
+    const int q0 = (blockIdx.x % tiles_q) * MQ;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lr = lane & 31, lk = lane >> 5;
+    const float* xb = x + (int64_t)b * D * N;
+    const float* sqb = sq + (int64_t)b * N;
+    const int qi = q0 + lr;
+    const bool qok = qi < N;
+    float bq[KSTEPS];
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; ++kk) {
+        const int d = 2 * kk + lk;
+        bq[kk] = (qok && d < D) ? xb[(int64_t)d * N + qi] : 0.f;
+    }
+    const float sq_i = qok ? sqb[qi] : 0.f;
+    const unsigned long long WORST = knn_key(-INFINITY, 0x7fffffff);
+    unsigned long long lst[32];                                        // sorted, best first; entries >= KK stay WORST
+#pragma unroll
+    for (int m = 0; m < 32; ++m) lst[m] = WORST;
+
+    const int ntile = (N + 31) / 32;
+    for (int t = w; t < ntile; t += MW) {
+        const int c0 = t * 32;
+        const int ci = c0 + lr;
+        const bool cok = ci < N;
+        float af[KSTEPS];
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) {
+            const int d = 2 * kk + lk;
+            af[kk] = (cok && d < D) ? xb[(int64_t)d * N + ci] : 0.f;
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk], bq[kk], acc, 0, 0, 0);
+        unsigned long long key[16];
+        unsigned long long best = WORST;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = c0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            const float sq_j = j < N ? sqb[j] : 0.f;
+            const float inner = -2.0f * acc[r];
+            const float tt = (-sq_j) - inner;
+            const float sc = j < N ? tt - sq_i : -INFINITY;
+            key[r] = j < N ? knn_key(sc, j) : WORST;
+            best = key[r] > best ? key[r] : best;
+        }
+        if (!__any(best > lst[KK - 1])) continue;                      // nothing in this tile reaches any list of the wave
+        // bitonic sort of the 16 keys, best first
+#pragma unroll
+        for (int kb = 2; kb <= 16; kb <<= 1)
+#pragma unroll
+            for (int jb = kb >> 1; jb > 0; jb >>= 1)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int l = i ^ jb;
+                    if (l > i) {
+                        if ((i & kb) == 0) { KNN_CE(key[i], key[l]) } else { KNN_CE(key[l], key[i]) }
+                    }
+                }
+        // the 32 best of list (32, padded) and tile (16, padded to 32): C[i] = max(A[i], B[31 - i]) is bitonic
+#pragma unroll
+        for (int i = 16; i < 32; ++i) {
+            const unsigned long long bkey = key[31 - i];
+            lst[i] = bkey > lst[i] ? bkey : lst[i];
+        }
+        // bitonic merge, best first
+#pragma unroll
+        for (int jb = 16; jb > 0; jb >>= 1)
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const int l = i ^ jb;
+                if (l > i) { KNN_CE(lst[i], lst[l]) }
+            }
+#pragma unroll
+        for (int m = KK; m < 32; ++m) lst[m] = WORST;                  // only the KK best survive a tile
+    }
+#pragma unroll
+    for (int m = 0; m < KK; ++m) lkey[lr][2 * w + lk][m] = lst[m];
+    __syncthreads();
+    if (threadIdx.x < MQ && q0 + (int)threadIdx.x < N) {               // 8-way merge of the sorted sub-lists
+        const int q = threadIdx.x;
+        int head[2 * MW];
+#pragma unroll
+        for (int u = 0; u < 2 * MW; ++u) head[u] = 0;
+        int64_t* o = idx + ((int64_t)b * N + q0 + q) * k;
+        for (int m = 0; m < k; ++m) {
+            unsigned long long bestk = 0ull;
+            int bu = 0;
+#pragma unroll
+            for (int u = 0; u < 2 * MW; ++u) {
+                const int h = head[u];
+                const unsigned long long v = h < KK ? lkey[q][u][h] : 0ull;
+                if (v > bestk) { bestk = v; bu = u; }
+            }
+#pragma unroll
+            for (int u = 0; u < 2 * MW; ++u) head[u] += (u == bu) ? 1 : 0;
+            o[m] = (int64_t)(0xFFFFFFFFu - (unsigned)(bestk & 0xFFFFFFFFull));
+        }
+    }
+}
+
 // Queued variant: one wave = 32 queries x ALL candidate tiles, so a query's candidates are split over only
 // two lists (the lane halves), each walked in ascending index order.  A score that beats the lane's current k-th best is
 // only APPENDED to a per-lane LDS queue (two predicated stores); the ~120-instruction sorted insertion runs in batches,
@@ -379,15 +508,21 @@ template <int KSTEPS>
 int launch_knn_mfma(const float* x, const float* sq, int B, int D, int N, int k, int64_t* idx, hipStream_t st) {
     const int tiles_q = (N + MQ - 1) / MQ;
     const dim3 grid((unsigned)(B * tiles_q));
-    // Measured (MI355X): with one wave per SIMD (B*N/32 <= 1024 waves, k <= 20) the two kernels tie (B=32, N=1024, k=20:
-    // 167 vs 159 us at D=3, 229 vs 247 us at D=63); the queued kernel wins as soon as there are more waves than SIMDs
-    // (B=512: 1.51 vs 1.73 ms, 2.37 vs 3.50 ms) or the lists get longer (N=2048, k=40: 0.39 vs 0.82 ms, 0.50 vs 0.89 ms).
+    // Measured (MI355X, us): k = 20, N = 1024     B=32 D=3   B=32 D=63   B=512 D=3   B=512 D=63
+    //   sorting-network kernel (4 waves)            96        168         1118        2324
+    //   per-score insertion kernel (4 waves)       156        243         1729        3500
+    //   queued single-wave kernel                  167        229         1508        2274
+    // and for N = 2048, k = 40 (lists longer than the 32-wide merge network): queued 390-500 us, insertion 817-894 us.
+    // So: k <= 32 -> sorting network, k > 32 -> queued kernel.
     const char* e = getenv("HPCS_KNN_KERNEL");     // tiled|queue overrides the choice (A/B tests; read on every call)
-    const int force = !e ? 0 : (e[0] == 't' ? 1 : 2);
-    const bool tiled = force == 1 || (force == 0 && k <= 20 && (long)B * tiles_q <= 1024);
+    const int force = !e ? 0 : (e[0] == 't' ? 1 : (e[0] == 'i' ? 3 : 2));      // tiled (sorting network) | insert | queue
+    const bool tiled = force == 1 || force == 3 || (force == 0 && k <= 32);
 #define HPCS_KNNM_CASE(KK)                                                                                   \
     if (k <= KK) {                                                                                            \
-        if (tiled)                                                                                            \
+        if (tiled && KK <= 32 && force != 3)                                                                  \
+            hipLaunchKernelGGL((knn_mfma_sort_kernel<KSTEPS, (KK <= 32 ? KK : 32)>), grid, dim3(MW * 64), 0, st, x, sq, D, N, k, \
+                               idx);                                                                          \
+        else if (tiled)                                                                                       \
             hipLaunchKernelGGL((knn_mfma_kernel<KSTEPS, KK>), grid, dim3(MW * 64), 0, st, x, sq, D, N, k, idx); \
         else                                                                                                  \
             hipLaunchKernelGGL((knn_mfma_queue_kernel<KSTEPS, KK, 1>), grid, dim3(64), 0, st, x, sq, D, N, k, idx); \

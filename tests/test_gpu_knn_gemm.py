@@ -33,7 +33,7 @@ def test_knn_bit_exact(B, D, N, k, seed):
     assert torch.equal(got, want)
 
 
-@pytest.mark.parametrize("kernel", ["tiled", "queue"])
+@pytest.mark.parametrize("kernel", ["tiled", "insert", "queue"])
 def test_knn_both_mfma_kernels_bit_exact(kernel, monkeypatch):
     """The two MFMA selection kernels (interleaved 4-wave tiles / one wave with per-lane queues) are chosen by problem
     size; both must reproduce the oracle on every shape, duplicates included."""
