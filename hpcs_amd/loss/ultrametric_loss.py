@@ -348,7 +348,8 @@ class MetricHyperbolicLoss(torch.nn.Module):
     def normalize_embeddings(self, embeddings):
         """Unit rows times clamp(scale, 1e-4, 1) (ultrametric_loss.py:139-143)."""
         s = self._scale_tensor(embeddings)
-        return L2RowsFn.apply(embeddings) * torch.clamp(s, 1e-4, 1)
+        rows = embeddings.reshape(-1, embeddings.shape[-1])          # F.normalize(dim=-1) semantics for [.., E]
+        return (L2RowsFn.apply(rows) * torch.clamp(s, 1e-4, 1)).reshape(embeddings.shape)
 
 
 class HierarchicalMetricHyperbolicLoss(MetricHyperbolicLoss):

@@ -50,13 +50,15 @@ def to_categorical(y, num_classes):
 class HypHCStep(torch.nn.Module):
     def __init__(self, nn_feat, nn_emb, hyp_size, num_class, num_categories=16, lr=1e-3, margin=0.5, t_per_anchor=50,
                  fraction=1.2, temperature=0.05, anneal_factor=0.5, trade_off=0.1, miner=True, cosface=True,
-                 train_rotation="so3", rng="device", fused_filter=True, hierarchical=False, hierarchy_list=None):
+                 train_rotation="so3", rng="device", fused_filter=True, hierarchical=False, hierarchy_list=None,
+                 test_rotation="so3"):
         super().__init__()
         self.nn_feat = nn_feat
         self.nn_emb = nn_emb
         self.num_categories = num_categories
         self.trade_off = trade_off
         self.train_rotation = train_rotation
+        self.test_rotation = test_rotation
         self.scale = torch.nn.Parameter(torch.Tensor([1e-3]), requires_grad=True)        # base_hyp_hc.py:62
         common = dict(margin=margin, t_per_anchor=t_per_anchor, fraction=fraction, scale=self.scale,
                       temperature=temperature, anneal_factor=anneal_factor, num_class=num_class, embedding_size=hyp_size,
@@ -102,6 +104,42 @@ class HypHCStep(torch.nn.Module):
             from .loss.ultrametric_loss import class_metrics
             acc, iou = class_metrics(self.metric_hyp_loss.loss_cosface.last_logits, y)
             out["acc"], out["iou"] = acc, iou
+        return out
+
+    # ---- test-time path (base_hyp_hc.py:81-86, 120-141, 194-200) ----
+    def _decode_linkage(self, leaves_embeddings):
+        """One cloud [N,E] -> linkage matrix as a host array, like the reference; batches: decode_linkage_batch."""
+        return self.decode_linkage_batch(leaves_embeddings.unsqueeze(0))[0].cpu().numpy()
+
+    def decode_linkage_batch(self, x_poincare):
+        """x_poincare [B,N,E] -> Z [B,N-1,4] fp64 on the device (hpcs_complete_linkage: one workgroup per cloud)."""
+        from .decode import decode_linkage
+        return decode_linkage(x_poincare, self.metric_hyp_loss)
+
+    @torch.no_grad()
+    def test_step(self, points, label, targets, index="iou", rot=None):
+        """forward(testing=True) + the scoring loop of test_step: losses, metrics, embeddings, linkage matrices and the
+        per-cloud best cut, everything on the device; `score` is the batch mean of the best scores (base_hyp_hc.py:241)."""
+        from .decode import optimal_k
+        if self.test_rotation == "so3":                         # shapenet_hyp_hc.py:58-69
+            self._rot_calls += 1
+            x = rotate_to_channels_first(points, rot=rot, seed=self._rot_seed + self._rot_calls)
+        else:
+            x = points.transpose(2, 1).contiguous().float()
+        decode = to_categorical(label, self.num_categories)
+        x_euclidean = self.nn_feat(x, decode)
+        x_poincare = self.nn_emb(x_euclidean) if self.nn_emb is not None else x_euclidean
+        y = targets.reshape(-1).long()
+        loss = self.metric_hyp_loss.compute_loss(x_euclidean.reshape(-1, x_euclidean.shape[-1]),
+                                                 x_poincare.reshape(-1, x_poincare.shape[-1]), y)
+        out = {"loss_metric": loss["loss_metric"]["losses"], "loss_hyp": loss["loss_hyp"]["losses"] * self.trade_off}
+        if hasattr(self.metric_hyp_loss, "loss_cosface"):
+            from .loss.ultrametric_loss import class_metrics
+            out["acc"], out["iou"] = class_metrics(self.metric_hyp_loss.loss_cosface.last_logits, y)
+        Z = self.decode_linkage_batch(x_poincare)
+        pred, best_k, best_score = optimal_k(targets, Z, index=index)
+        out.update(x_euclidean=x_euclidean, x_poincare=x_poincare, linkage_matrix=Z, best_pred=pred, best_k=best_k,
+                   best_score=best_score, score=best_score.float().mean())
         return out
 
     def training_step(self, points, label, targets, targets_host=None, rot=None, drop_masks=None):

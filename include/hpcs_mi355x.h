@@ -318,6 +318,26 @@ int hpcs_radam_step(const hpcs_radam_desc* desc_dev, int n_tensors, int64_t tota
 int hpcs_so3_rotate_points(const float* points, int B, int N, uint64_t seed, const float* rot_in, float* x_out,
                            float* rot_out, hpcs_stream_t stream);
 
+/* ---- next row f4: test-time decode ---------------------------------------------------------------------------------
+ * hpcs_complete_linkage replaces BaseSimilarityHypHC._decode_linkage (hpcs/models/base_hyp_hc.py:81-86) for a whole
+ * batch: Z[b] = scipy.cluster.hierarchy.linkage(leaves[b], method='complete', metric='cosine'), bit-identical
+ * (fp64 cosine distances in scipy's rounding sequence, nearest-neighbour chain, stable sort by height, union-find
+ * labels).  leaves [B,N,E] fp32 = project(normalize_embeddings(x_poincare)); Z [B,N-1,4] fp64 rows
+ * (cluster a, cluster b, height, size); status [B] int32: 0 ok, bit 0 = a non-finite distance (scipy raises
+ * ValueError), bit 2 = chain step bound exceeded (cannot happen for finite input).
+ * N <= 2048.  ws: hpcs_complete_linkage_workspace bytes (the B*N*N fp64 distance matrices; destroyed). */
+size_t hpcs_complete_linkage_workspace(int B, int N);
+int hpcs_complete_linkage(const float* leaves, int B, int N, int E, double* Z, int32_t* status, void* ws,
+                          size_t ws_bytes, hpcs_stream_t stream);
+/* hpcs_optimal_k replaces get_optimal_k(y, linkage_matrix, index) (hpcs/utils/scores.py:141-177, remap_labels
+ * :124-139) for a whole batch: for k = 1..K_true+4, y_pred = fcluster(Z, k, 'maxclust') - 1 with scipy's cluster
+ * numbering; index_mode 0 ('iou'): per-part arg-max IoU remap then one-hot Jaccard; 1 ('ri'): adjusted Rand index;
+ * the first k with the strictly best score wins.  y [B,N] int64 labels in [0, num_labels), num_labels <= 1024, at
+ * most 64 distinct per cloud; best_pred [B,N] int32 (-1 when no k scored > 0), best_k [B] int32, best_score [B] fp64;
+ * status [B]: 0 ok, 2 = label out of range, 3 = too many parts for this kernel. */
+int hpcs_optimal_k(const double* Z, const int64_t* y, int B, int N, int num_labels, int index_mode,
+                   int32_t* best_pred, int32_t* best_k, double* best_score, int32_t* status, hpcs_stream_t stream);
+
 /* flat fp32 helpers used by the data-parallel wrapper (gradient bucket pack/unpack+scale) */
 int hpcs_scale_inplace(float* x, int64_t n, float s, hpcs_stream_t stream);
 

@@ -1,0 +1,153 @@
+"""GPU parity for the test-time decode (row f4), through the C ABI: hpcs_complete_linkage against the real
+scipy.cluster.hierarchy.linkage (bit-identical linkage matrices) and hpcs_optimal_k against the oracle restatement, the
+live scipy/sklearn loop and the reference-made golden vectors."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from _det import det_int, det_normalish
+from hpcs_amd import _lib, decode
+from oracle import decode as OD
+
+pytestmark = pytest.mark.gpu
+dev = "cuda"
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(HERE, "golden", "decode.npz"))
+
+
+def _leaves(B, N, E, seed, dup=0, scale=1e-3):
+    x = det_normalish((B, N, E), seed)
+    if dup:
+        x[:, ::dup] = x[:, :1]
+        x[:, 1::dup] = -x[:, :1]
+    return np.stack([OD.decode_leaves(x[b].numpy(), scale) for b in range(B)])
+
+
+@pytest.mark.parametrize("B,N,E,dup", [(3, 256, 32, 0), (2, 200, 2, 5), (2, 128, 7, 0), (2, 130, 33, 3), (2, 65, 1, 0),
+                                       (1, 2, 4, 0), (2, 3, 5, 0), (2, 1024, 32, 0), (1, 2048, 32, 0), (1, 1500, 2, 4)])
+def test_complete_linkage_equals_scipy(B, N, E, dup):
+    from scipy.cluster.hierarchy import linkage
+    leaves = _leaves(B, N, E, 4000 + N + E, dup)
+    Z = decode.complete_linkage(torch.from_numpy(leaves).to(dev)).cpu().numpy()
+    for b in range(B):
+        want = linkage(leaves[b], method="complete", metric="cosine")
+        assert np.array_equal(Z[b], want), (b, np.abs(Z[b] - want).max())
+
+
+def test_complete_linkage_golden_and_restatement(gold):
+    for name in ("a", "b", "c"):
+        leaves = gold[f"{name}_leaves"]
+        Z = decode.complete_linkage(torch.from_numpy(leaves).to(dev)).cpu().numpy()      # single-cloud form [N,E]
+        assert np.array_equal(Z, gold[f"{name}_Z"])
+        assert np.array_equal(Z, OD.complete_linkage(leaves))
+
+
+def test_decode_linkage_from_embeddings():
+    """_decode_linkage end to end: normalise + project on the device (fp32, matches torch CPU to rounding), then the
+    linkage of THOSE leaves is bit-identical to scipy's."""
+    from scipy.cluster.hierarchy import linkage
+    from hpcs_amd.distances.poincare import project
+    from hpcs_amd.loss.ultrametric_loss import MetricHyperbolicLoss
+    scale = torch.nn.Parameter(torch.tensor([0.37], device=dev))
+    loss = MetricHyperbolicLoss(scale=scale, num_class=4, embedding_size=16, cosface=True, miner=True).to(dev)
+    x = (det_normalish((2, 192, 16), 77) * 0.3).to(dev)
+    leaves = project(loss.normalize_embeddings(x)).cpu().numpy()
+    for b in range(2):
+        np.testing.assert_allclose(leaves[b], OD.decode_leaves(x[b].cpu().numpy(), 0.37), rtol=2e-6, atol=1e-9)
+    Z = decode.decode_linkage(x, loss).cpu().numpy()
+    for b in range(2):
+        assert np.array_equal(Z[b], linkage(leaves[b], method="complete", metric="cosine"))
+
+
+@pytest.mark.parametrize("index", ["iou", "ri"])
+@pytest.mark.parametrize("B,N,E,dup,nlab", [(3, 256, 32, 0, 4), (2, 200, 2, 5, 3), (2, 1024, 32, 0, 6), (1, 2048, 8, 0, 50),
+                                            (2, 64, 3, 0, 1)])
+def test_optimal_k_equals_oracle_and_thirdparty(B, N, E, dup, nlab, index):
+    leaves = _leaves(B, N, E, 5000 + N + E, dup)
+    Z = decode.complete_linkage(torch.from_numpy(leaves).to(dev))
+    # spatially coherent parts with gaps in the label values (remap_labels) and a different part set per cloud
+    y = np.stack([((leaves[b][:, 0] > 0).astype(np.int64) + 2 * (leaves[b][:, (1 + b) % E] > 0) +
+                   det_int((N,), 60 + b, max(nlab - 3, 1)).numpy()) % nlab * 3 + 2 for b in range(B)])
+    pred, k, score = decode.optimal_k(torch.from_numpy(y).to(dev), Z, index=index)
+    pred, k, score = pred.cpu().numpy(), k.cpu().numpy(), score.cpu().numpy()
+    Zh = Z.cpu().numpy()
+    for b in range(B):
+        wp, wk, ws = OD.optimal_k(y[b], Zh[b], index)
+        assert int(k[b]) == wk and float(score[b]) == ws, (b, k[b], wk, score[b], ws)
+        if wk:
+            assert np.array_equal(pred[b], wp)
+        else:
+            assert (pred[b] == -1).all()
+        if N <= 256:                                    # the slow literal loop on scipy + sklearn
+            tp, tk, ts = OD.optimal_k_thirdparty(y[b], Zh[b], index)
+            assert int(k[b]) == tk and float(score[b]) == ts and (tk == 0 or np.array_equal(pred[b], tp))
+
+
+def test_optimal_k_golden_and_mirror(gold):
+    import make_golden_decode as MGD
+    from hpcs_amd.utils.scores import get_optimal_k, remap_labels
+    for name in ("a", "b", "c"):
+        _, y, _ = MGD.inputs(name)
+        for index in ("iou", "ri"):
+            pred, k, score = get_optimal_k(y, gold[f"{name}_Z"], index)          # host arrays in, host values out
+            assert k == int(gold[f"{name}_{index}_k"]) and score == float(gold[f"{name}_{index}_score"])
+            assert np.array_equal(pred, gold[f"{name}_{index}_pred"])
+        assert np.array_equal(remap_labels(y).numpy(), OD.remap_labels(y.numpy()))
+
+
+def test_decode_errors():
+    with pytest.raises(_lib.HpcsNativeError):
+        decode.complete_linkage(torch.zeros(1, 16, 4))                               # CPU tensor: no fallback
+    with pytest.raises(_lib.HpcsNativeError):
+        decode.complete_linkage(torch.randn(1, 2049, 4, device=dev))                 # beyond the kernel's LDS plan
+    x = torch.randn(2, 32, 4, device=dev)
+    x[1, 5] = 0.0                                                                    # zero row: 0/0 cosine
+    with pytest.raises(ValueError):
+        decode.complete_linkage(x)
+    Z = decode.complete_linkage(torch.randn(1, 32, 4, device=dev))
+    with pytest.raises(ValueError):
+        decode.optimal_k(torch.full((1, 32), 7, device=dev), Z, num_labels=4)        # label outside [0, num_labels)
+    with pytest.raises(ValueError):
+        decode.optimal_k(torch.zeros(1, 32, dtype=torch.long, device=dev), Z, index="nmi")
+
+
+def test_test_step_end_to_end():
+    """HypHCStep.test_step: extractor -> embedding -> losses/metrics -> batch linkage -> best cut, checked against the
+    host pipeline (scipy + oracle) run on the embeddings the step produced."""
+    from scipy.cluster.hierarchy import linkage
+    from hpcs_amd.nn.dgcnn import VN_DGCNN_partseg
+    from hpcs_amd.nn.hyperbolic import ExpMap
+    from hpcs_amd.step import HypHCStep
+    torch.manual_seed(0)
+    B, N, E, C = 2, 128, 8, 4
+    feat = VN_DGCNN_partseg(in_channels=3, out_features=E, k=10, dropout=0.5, pooling="mean", num_categories=16)
+    step = HypHCStep(feat, ExpMap(), hyp_size=E, num_class=C, num_categories=16, test_rotation="none").to(dev).configure()
+    step.eval()
+    pts = det_normalish((B, N, 3), 21).to(dev)
+    label = torch.zeros(B, dtype=torch.long, device=dev)
+    targets = ((pts[:, :, 0] > 0).long() + 2 * (pts[:, :, 2] > 0).long())
+    out = step.test_step(pts, label, targets)
+    assert torch.isfinite(out["loss_metric"]) and torch.isfinite(out["loss_hyp"]) and 0 <= float(out["acc"]) <= 1
+    xp = out["x_poincare"]
+    scale = float(step.scale.detach().cpu())
+    from hpcs_amd.distances.poincare import project
+    leaves = project(step.metric_hyp_loss.normalize_embeddings(xp)).cpu().numpy()
+    Z = out["linkage_matrix"].cpu().numpy()
+    scores = []
+    for b in range(B):
+        assert np.array_equal(Z[b], linkage(leaves[b], method="complete", metric="cosine"))
+        wp, wk, ws = OD.optimal_k(targets[b].cpu().numpy(), Z[b], "iou")
+        assert int(out["best_k"][b]) == wk and float(out["best_score"][b]) == ws
+        assert np.array_equal(out["best_pred"][b].cpu().numpy(), wp)
+        scores.append(ws)
+    assert abs(float(out["score"]) - float(np.mean(scores))) < 1e-6
+    assert np.array_equal(step._decode_linkage(xp[0]), Z[0])
+    assert scale > 0
