@@ -447,27 +447,39 @@ __global__ __launch_bounds__(256) void gemm_nt_edge_kernel(
 }
 
 // Sums the split partials in a FIXED order (deterministic).  64 outputs per workgroup, 16 waves each own every
-// 16th split, the 16 partial sums are then added in wave order.
-__global__ __launch_bounds__(1024) void split_reduce_kernel(const float* __restrict__ part, int nsplit, int M, int Kx,
-                                                            float* __restrict__ dW, int lddw, int accumulate) {
+// 16th split, the 16 partial sums are then added in wave order.  blockIdx.y = slice of `slice_len` splits: a launch with
+// gridDim.y > 1 writes one partial per slice to `stage` ([slices][M*Kx]) instead of dW (first level of the two-level
+// reduction used when few outputs face many splits: 42x42 EdgeConv gradients over ~1900 splits kept 28 workgroups busy
+// for 55-100 us; two levels spread the same reads over ~900 workgroups).
+__global__ __launch_bounds__(1024) void split_reduce_kernel(const float* __restrict__ part, int nsplit, int slice_len, int M,
+                                                            int Kx, float* __restrict__ dW, int lddw, int accumulate,
+                                                            float* __restrict__ stage) {
     __shared__ float sh[16][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t e = (int64_t)blockIdx.x * 64 + lane;
     const int64_t ne = (int64_t)M * Kx;
+    const int s0 = blockIdx.y * slice_len, s1 = min(nsplit, s0 + slice_len);
     float s = 0.f;
     if (e < ne)
-        for (int i = w; i < nsplit; i += 16) s += part[(int64_t)i * ne + e];
+        for (int i = s0 + w; i < s1; i += 16) s += part[(int64_t)i * ne + e];
     sh[w][lane] = s;
     __syncthreads();
     if (w == 0 && e < ne) {
         float t = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) t += sh[i][lane];
-        const int row = (int)(e / Kx), col = (int)(e % Kx);
-        float* d = dW + (int64_t)row * lddw + col;
-        *d = accumulate ? *d + t : t;
+        if (stage) {
+            stage[(int64_t)blockIdx.y * ne + e] = t;
+        } else {
+            const int row = (int)(e / Kx), col = (int)(e % Kx);
+            float* d = dW + (int64_t)row * lddw + col;
+            *d = accumulate ? *d + t : t;
+        }
     }
 }
+
+constexpr int SR_SLICES = 32;   // first-level slices of the two-level split reduction
+inline bool sr_two_level(int nsplit, int64_t ne) { return nsplit >= 256 && ne <= 64 * 512; }
 
 constexpr int NT_BKC = 32;      // 64-wide steps measured: +9 % on the HBM-bound EdgeConv shapes, -10 % on the large ones
 
@@ -580,7 +592,8 @@ extern "C" int hpcs_gemm_tn(const float* At, int lda, const float* Bm, int ldb, 
 extern "C" size_t hpcs_gemm_nt_workspace(int M, int Kx, int Nc, int n_outer, int n_inner) {
     if (M <= 0 || Kx <= 0 || Nc <= 0 || n_outer <= 0 || n_inner <= 0) return 0;
     const NtPlan p = nt_plan(M, Kx, Nc, n_outer * n_inner);
-    return (size_t)p.nsplit * M * Kx * sizeof(float);
+    const size_t stage = sr_two_level(p.nsplit, (int64_t)M * Kx) ? (size_t)SR_SLICES * M * Kx : 0;
+    return ((size_t)p.nsplit * M * Kx + stage) * sizeof(float);
 }
 
 extern "C" int hpcs_gemm_nt(const float* G, int ldg, int64_t strideG_o, int64_t strideG_i, const float* X, int ldx,
@@ -591,7 +604,9 @@ extern "C" int hpcs_gemm_nt(const float* G, int ldg, int64_t strideG_o, int64_t 
         return HPCS_ERR_SHAPE;
     const int nb = n_outer * n_inner;
     const NtPlan p = nt_plan(M, Kx, Nc, nb);
-    if (ws_bytes < (size_t)p.nsplit * M * Kx * sizeof(float)) return HPCS_ERR_WORKSPACE;
+    const bool two_level = sr_two_level(p.nsplit, (int64_t)M * Kx);
+    if (ws_bytes < ((size_t)p.nsplit * M * Kx + (two_level ? (size_t)SR_SLICES * M * Kx : 0)) * sizeof(float))
+        return HPCS_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int vecG = (ldg % 4 == 0) && (strideG_o % 4 == 0) && (strideG_i % 4 == 0) && aligned16(G);
     const int vecX = (ldx % 4 == 0) && (strideX_o % 4 == 0) && (strideX_i % 4 == 0) && aligned16(X);
@@ -610,8 +625,18 @@ extern "C" int hpcs_gemm_nt(const float* G, int ldg, int64_t strideG_o, int64_t 
                            p.units_per_batch, p.nsplit, (float*)ws, p.tilesM, p.tilesK, vecG, vecX);
     HPCS_CHECK_LAUNCH();
     const int64_t ne = (int64_t)M * Kx;
-    hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)hpcs_cdiv(ne, 64)), dim3(1024), 0, st, (const float*)ws,
-                       p.nsplit, M, Kx, dW, lddw, accumulate);
+    if (two_level) {
+        float* stage = (float*)ws + (size_t)p.nsplit * ne;
+        const int slice_len = hpcs_cdiv(p.nsplit, SR_SLICES), slices = hpcs_cdiv(p.nsplit, slice_len);
+        hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)hpcs_cdiv(ne, 64), (unsigned)slices), dim3(1024), 0, st,
+                           (const float*)ws, p.nsplit, slice_len, M, Kx, dW, lddw, 0, stage);
+        HPCS_CHECK_LAUNCH();
+        hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)hpcs_cdiv(ne, 64)), dim3(1024), 0, st, (const float*)stage,
+                           slices, slices, M, Kx, dW, lddw, accumulate, (float*)nullptr);
+    } else {
+        hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)hpcs_cdiv(ne, 64)), dim3(1024), 0, st, (const float*)ws,
+                           p.nsplit, p.nsplit, M, Kx, dW, lddw, accumulate, (float*)nullptr);
+    }
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;
 }
