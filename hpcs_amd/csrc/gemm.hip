@@ -10,6 +10,8 @@
 // conflict-free ds_read_b32 per lane (lanes 0-31 = 32 consecutive floats of row k, lanes 32-63 = row k+1).
 // Global->LDS goes through registers, double-buffered, one barrier per K step.
 // Block ids are remapped so that the row tiles sharing one activation panel run on the same XCD (L2 reuse).
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -93,9 +95,18 @@ __global__ __launch_bounds__(WM* WN * 64, 4) void gemm_tn_kernel(
     lstore(0);
     __syncthreads();
     const int lr = lane & 31, lk = lane >> 5;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) gload((kt + 1) * BK);
+    // 32x32 sub-tiles that lie entirely in the padding of an edge tile (M = 341 / 682 leave 32-64 dead rows in the last
+    // 128-row tile) issue no MFMA: the matrix pipe of that SIMD goes to the other resident workgroup instead
+    bool live[TM][TN];
+    bool all_live = true;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            live[i][j] = (m0 + wm * (BM / WM) + i * 32 < M) && (n0 + wn * (BN / WN) + j * 32 < Nc);
+            all_live = all_live && live[i][j];
+        }
+    auto mma = [&](int buf, auto full) {
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
             float a[TM], b[TN];
@@ -107,8 +118,15 @@ __global__ __launch_bounds__(WM* WN * 64, 4) void gemm_tn_kernel(
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    if (decltype(full)::value || live[i][j])
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+    };
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload((kt + 1) * BK);
+        if (all_live) mma(buf, std::true_type{});
+        else mma(buf, std::false_type{});
         if (kt + 1 < nk) lstore(buf ^ 1);
         __syncthreads();
     }

@@ -70,7 +70,7 @@ class HypHCStep(torch.nn.Module):
         self.lr = lr
         self._rot_seed = int(torch.initial_seed()) & (2 ** 62 - 1)
         self._rot_calls = 0
-        self.side_stream_wgrad = True
+        self.side_stream_wgrad = __import__("os").environ.get("HPCS_SIDE_STREAM", "1") != "0"   # 0: serial (profiling)
         self.metrics = True
         self.optimizer = None
         self.bucket = None
