@@ -243,6 +243,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(
     const int wm = wave / WN, wn = wave % WN;
     const int lr = lane & 31, lk = lane >> 5;
 
+    const bool wave_live = (TM * TN > 1) || ((m0 + wm * (BM / WM) < M) && (x0 + wn * (BN / WN) < Kx));
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
             }
-        } else
+        } else if (wave_live)              // a wave whose 32x32 block is all padding (Kx = 341: columns 352..383) idles
 #pragma unroll
         for (int k4 = 0; k4 < BKC / 4; ++k4) {               // columns 4*k4 .. 4*k4+3 = k-steps 2*k4 and 2*k4+1
             float4 a4[TM], b4[TN];
