@@ -163,6 +163,28 @@ def cpu_baseline(args):
             "s_per_step": round(dt, 3)}
 
 
+def knn_steady_state(dev, N, k, B=4096, D=3, reps=5):
+    """at 32 clouds the kNN launch is in the launch-latency regime, so the kernel is also timed at B=4096
+    (D=3: 50 MB of points in, 0.67 GB of int64 indices out) with HIP events on the launch stream."""
+    from hpcs_amd import _lib
+    x = torch.randn(B, D, N, device=dev)
+    idx = torch.empty(B, N, k, dtype=torch.int64, device=dev)
+    nbytes = _lib.call("hpcs_knn_workspace", B, N)
+    ws = torch.empty(nbytes // 4, device=dev)
+    _lib.call("hpcs_knn", x, B, D, N, k, idx, ws, nbytes)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        _lib.call("hpcs_knn", x, B, D, N, k, idx, ws, nbytes)
+    e1.record()
+    torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) * 1e-3 / reps
+    byts, flops = B * N * (4 * D + 8 * k), 2.0 * D * N * N * B
+    return {"B": B, "D": D, "N": N, "k": k, "ms_per_launch": round(t * 1e3, 3), "achieved_GBs": round(byts / t / 1e9, 1),
+            "frac_hbm": round(byts / t / 1e9 / HBM_PEAK_GBS, 4), "fp32_tflops": round(flops / t / 1e12, 2),
+            "clouds_per_s": round(B / t)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -327,14 +349,17 @@ def main():
                                          "triplets_sampled": T_s,
                                          "triplets_kept": kept,
                                          "note": "float atomics run at ~1.3 TB/s of added bytes chip-wide (MI355X_MICROARCH)"}
-        out["roofline_knn"] = {"kernel": "knn_sumsq_kernel + knn_mfma_kernel (hpcs_knn, D=3 and D=63 launches)",
+        out["roofline_knn"] = {"kernel": "knn_sumsq_kernel + knn_mfma_sort_kernel (hpcs_knn, D=3 and D=63 launches)",
                                "bound": "hbm",
                                "achieved": round(kn_bytes / kn_time / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(kn_bytes / kn_time / 1e9 / HBM_PEAK_GBS, 5), "traffic": pmc_traffic("knn_mfma_kernel"),
+                               "frac": round(kn_bytes / kn_time / 1e9 / HBM_PEAK_GBS, 5),
+                               "traffic": pmc_traffic("knn_mfma_sort_kernel") or pmc_traffic("knn_mfma_kernel"),
                                "algorithmic_bytes_per_launch": round(kn_bytes / len(kn)),
                                "launches": len(kn), "avg_launch_us": round(1e6 * kn_time / len(kn), 2),
                                "fp32_tflops": round(kn_flops / kn_time / 1e12, 3), "measured": EXTRA_NOTE,
                                "note": "arithmetic intensity 36-313 flop/B: bound by the VALU top-k selection, not by HBM"}
+        if world == 1:
+            out["roofline_knn"]["steady_state"] = knn_steady_state(device, args.points, args.k)
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args)
     print(json.dumps(out))
