@@ -8,6 +8,8 @@
 // All kernels are HBM-bound streaming passes over [B,C,3,L] tensors with L contiguous: threads run along L
 // (coalesced 4-byte lanes, three xyz planes L apart), one grid.y slice per channel, per-channel BatchNorm
 // reductions accumulate in double through one atomic per workgroup.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -1331,6 +1333,129 @@ extern "C" int hpcs_edge_gather_fwd(const float* x, const int64_t* idx, int B, i
     return HPCS_OK;
 }
 
+// ---- backward of get_graph_feature through the INVERSE graph (N <= 1024, N*k <= 20480: the BASELINE geometry) ------------
+// The scatter-add over idx is a gather over the transposed adjacency: gx[m] = sum over the edges e = (n, j) with
+// idx[n, j] = m of g_diff[e], plus the centre part sum_j (g_ctr[m, j] - g_diff[m, j]).  One workgroup per cloud builds the
+// transposed lists once per call (LDS counting sort, every list sorted by edge id so that the sums have a fixed order);
+// the reduction kernel then stages one N*k plane of `gout` in LDS per step (the next plane is already in flight in
+// registers) and every point adds up its own incoming edges: no atomics, no scratch memset, no fold pass, every byte of
+// `gout` read once.  Replaces centre pass + memset + atomic scatter + fold (57 + 10 + 160-200 + 15 us per 330 MB layer).
+constexpr int INV_T = 1024;
+constexpr int INV_MAXL = 20480;
+__global__ __launch_bounds__(INV_T) void knn_inverse_kernel(const int64_t* __restrict__ idx, int N, int k,
+                                                            int* __restrict__ in_ptr, unsigned short* __restrict__ in_edge) {
+    __shared__ int hist[INV_T + 1];
+    __shared__ int cursor[INV_T];
+    __shared__ int wsum[INV_T / 64];
+    __shared__ unsigned short ine[INV_MAXL];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int L = N * k;
+    const int64_t* ib = idx + (int64_t)b * L;
+    hist[tid] = 0;
+    __syncthreads();
+    for (int e = tid; e < L; e += INV_T) {
+        const int m = (int)ib[e];
+        if ((unsigned)m < (unsigned)N) atomicAdd(&hist[m], 1);        // kNN indices are cloud-local; anything else is dropped
+    }
+    __syncthreads();
+    // exclusive scan over the N (<= 1024) counts
+    const int cnt = tid < N ? hist[tid] : 0;
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wv; ++w) base += wsum[w];
+    const int start = base + incl - cnt;
+    cursor[tid] = start;
+    __syncthreads();
+    for (int e = tid; e < L; e += INV_T) {
+        const int m = (int)ib[e];
+        if ((unsigned)m < (unsigned)N) ine[atomicAdd(&cursor[m], 1)] = (unsigned short)e;
+    }
+    __syncthreads();
+    if (tid < N) {                                   // fixed summation order: every list ascending in the edge id
+        for (int i = start + 1; i < start + cnt; ++i) {
+            const unsigned short v = ine[i];
+            int j = i - 1;
+            while (j >= start && ine[j] > v) { ine[j + 1] = ine[j]; --j; }
+            ine[j + 1] = v;
+        }
+        in_ptr[(int64_t)b * (N + 1) + tid] = start;
+        if (tid == N - 1) in_ptr[(int64_t)b * (N + 1) + N] = start + cnt;
+    }
+    __syncthreads();
+    for (int e = tid; e < L; e += INV_T) in_edge[(int64_t)b * L + e] = ine[e];
+}
+
+// grid (groups, B): the workgroup walks planes p = group, group + groups, ... of cloud b (p = c*3 + a).
+__global__ __launch_bounds__(INV_T) void edge_gather_bwd_inv_kernel(const float* __restrict__ gout, const int* __restrict__ in_ptr,
+                                                                    const unsigned short* __restrict__ in_edge, int C, int N,
+                                                                    int k, float* __restrict__ gx) {
+    extern __shared__ float4 inv_lds[];
+    const int L = N * k, L4 = L >> 2;                // host guarantees L % 4 == 0
+    float* plane = reinterpret_cast<float*>(inv_lds);                                   // [L]
+    unsigned short* ine = reinterpret_cast<unsigned short*>(plane + L);                 // [L]
+    const int b = blockIdx.y, tid = threadIdx.x;
+    for (int e = tid; e < L; e += INV_T) ine[e] = in_edge[(int64_t)b * L + e];
+    int e0 = 0, e1 = 0;
+    if (tid < N) {
+        e0 = in_ptr[(int64_t)b * (N + 1) + tid];
+        e1 = in_ptr[(int64_t)b * (N + 1) + tid + 1];
+    }
+    constexpr int PF = INV_MAXL / 4 / INV_T;         // float4 prefetch registers per thread (5)
+    float4 pre[PF];
+    auto fetch = [&](int p, int half) {              // half 0: difference channels [0,C), 1: centre channels [C,2C)
+        const int c = p / 3, a = p % 3;
+        const float4* src = reinterpret_cast<const float4*>(gout + (((int64_t)b * 2 * C + half * C + c) * 3 + a) * L);
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int q = tid + i * INV_T;
+            pre[i] = q < L4 ? src[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int q = tid + i * INV_T;
+            if (q < L4) reinterpret_cast<float4*>(plane)[q] = pre[i];
+        }
+    };
+    auto own_sum = [&]() {                           // sum_j plane[tid*k + j]
+        float s = 0.f;
+        if (tid < N) {
+            const float4* r = reinterpret_cast<const float4*>(plane + tid * k);       // k % 4 == 0
+            for (int j = 0; j < (k >> 2); ++j) {
+                const float4 v = r[j];
+                s += (v.x + v.y) + (v.z + v.w);
+            }
+        }
+        return s;
+    };
+    const int planes = C * 3;
+    int p = blockIdx.x;
+    if (p < planes) fetch(p, 1);
+    for (; p < planes; p += gridDim.x) {
+        __syncthreads();                             // previous plane fully consumed
+        stash();                                     // centre plane
+        fetch(p, 0);
+        __syncthreads();
+        float s = own_sum();
+        __syncthreads();
+        stash();                                     // difference plane
+        if (p + (int)gridDim.x < planes) fetch(p + gridDim.x, 1);
+        __syncthreads();
+        s -= own_sum();
+        float g = 0.f;
+        for (int e = e0; e < e1; ++e) g += plane[ine[e]];
+        if (tid < N) gx[((int64_t)b * planes + p) * N + tid] = g + s;
+    }
+}
+
 extern "C" size_t hpcs_edge_gather_bwd_workspace(int B, int C, int N) {
     if (B <= 0 || C <= 0 || N <= 0) return 64;
     const int CP = (C * 3 + 15) / 16 * 16;
@@ -1346,6 +1471,27 @@ extern "C" int hpcs_edge_gather_bwd(const float* gout, const int64_t* idx, int B
     const int64_t L = (int64_t)N * k;
     const int CP = (C * 3 + 15) / 16 * 16;
     const bool vec = (k % 4 == 0) && (((uintptr_t)gout & 15u) == 0);
+    {   // inverse-graph path: the whole cloud's plane fits one workgroup's LDS
+        static const bool off = getenv("HPCS_EDGE_BWD_ATOMIC") != nullptr;
+        const size_t ptr_bytes = ((size_t)B * (N + 1) * sizeof(int) + 255) & ~(size_t)255;
+        const size_t need = ptr_bytes + (size_t)B * L * sizeof(unsigned short);
+        if (!off && vec && N <= INV_T && L <= INV_MAXL && (L % 4) == 0 && ws_bytes >= need) {
+            int* in_ptr = (int*)ws;
+            unsigned short* in_edge = (unsigned short*)((char*)ws + ptr_bytes);
+            hipLaunchKernelGGL(knn_inverse_kernel, dim3(B), dim3(INV_T), 0, ST, idx, N, k, in_ptr, in_edge);
+            HPCS_CHECK_LAUNCH();
+            const size_t lds = (size_t)L * (sizeof(float) + sizeof(unsigned short));
+            (void)hipFuncSetAttribute((const void*)edge_gather_bwd_inv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      INV_MAXL * 6);
+            int groups = 256 / B;                    // ~one workgroup per CU; each walks planes/groups planes of its cloud
+            if (groups < 1) groups = 1;
+            if (groups > C * 3) groups = C * 3;
+            hipLaunchKernelGGL(edge_gather_bwd_inv_kernel, dim3(groups, B), dim3(INV_T), lds, ST, gout, (const int*)in_ptr,
+                               (const unsigned short*)in_edge, C, N, k, gx);
+            HPCS_CHECK_LAUNCH();
+            return HPCS_OK;
+        }
+    }
     if (vec && k <= 64)
         hipLaunchKernelGGL(edge_gather_bwd_center_tile_kernel, dim3(hpcs_cdiv(N, 64), C, B), dim3(16 * k), 0, ST, gout, C, N, k, gx);
     else if (vec)

@@ -59,6 +59,36 @@ def test_get_graph_feature(golden, tag, C):
     close(xg.grad, xr.grad, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("B,C,N,k,hub", [(3, 21, 1024, 20, False), (2, 1, 1024, 20, True), (2, 5, 300, 8, True),
+                                         (1, 3, 1024, 16, False), (2, 4, 64, 12, False)])
+def test_graph_feature_backward_inverse_graph(B, C, N, k, hub):
+    """Backward of get_graph_feature at the BASELINE geometry (N*k <= 20480 takes the inverse-graph kernels: transposed
+    adjacency by an LDS counting sort, then an atomics-free gather with a fixed summation order) against the oracle's
+    autograd; `hub` sends a quarter of all edges to ONE point (in-degree ~ N*k/4) and leaves others without in-edges."""
+    from hpcs_amd.nn.dgcnn.utils.vn_dgcnn_util import get_graph_feature
+    x = det_normalish((B, C, 3, N), 900 + N + k)
+    idx = det_int((B, N, k), 901 + N, N)
+    if hub:
+        idx[:, ::2, ::2] = 7
+    w = det_uniform((B, 2 * C, 3, N, k), 902)
+    xg = x.to(dev).requires_grad_(True)
+    (get_graph_feature(xg, k=k, idx=idx.to(dev)) * w.to(dev)).sum().backward()
+    g1 = xg.grad.clone()
+    xg.grad = None
+    (get_graph_feature(xg, k=k, idx=idx.to(dev)) * w.to(dev)).sum().backward()
+    assert torch.equal(g1, xg.grad)                                  # no atomics: bit-reproducible
+    wd = w.double()
+    ref = torch.zeros(B, C * 3, N, dtype=torch.float64).scatter_add_(
+        2, idx.reshape(B, 1, N * k).expand(-1, C * 3, -1), wd[:, :C].reshape(B, C * 3, N * k))
+    ref = (ref + (wd[:, C:] - wd[:, :C]).sum(-1).reshape(B, C * 3, N)).reshape(B, C, 3, N)
+    if N <= 64:                                                      # and the oracle's own autograd on the small case
+        xr = x.double().requires_grad_(True)
+        (OE.graph_feature(xr, k, idx=idx) * wd).sum().backward()
+        assert float((xr.grad - ref).abs().max()) < 1e-12
+    err = (g1.cpu().double() - ref).abs().max()
+    assert float(err) <= 2e-6 * float(ref.abs().max()) * (1 + (N * k / 4 if hub else k) ** 0.5), float(err)
+
+
 def test_vn_linear_leaky_relu_dim5(golden):
     from hpcs_amd.nn.dgcnn.utils.vn_layers import VNLinearLeakyReLU
     x5 = det_normalish((2, 6, 3, 16, 4), 30)
