@@ -1456,6 +1456,60 @@ __global__ __launch_bounds__(INV_T) void edge_gather_bwd_inv_kernel(const float*
     }
 }
 
+// Same transposed-adjacency reduction for a tensor that has NO centre half: GPD [B,Ctot,3,N*k] -> gUV [B,2*Ctot,3,N] with
+// gU[m] = sum over the edges pointing at m (channels [0,Ctot)) and gV[n] = sum over the k edges leaving n (channels
+// [Ctot,2Ctot)).  One staged plane serves both sums.
+__global__ __launch_bounds__(INV_T) void edge_grad_reduce_inv_kernel(const float* __restrict__ GPD, const int* __restrict__ in_ptr,
+                                                                     const unsigned short* __restrict__ in_edge, int Ctot, int N,
+                                                                     int k, float* __restrict__ gUV) {
+    extern __shared__ float4 inv_lds[];
+    const int L = N * k, L4 = L >> 2;
+    float* plane = reinterpret_cast<float*>(inv_lds);
+    unsigned short* ine = reinterpret_cast<unsigned short*>(plane + L);
+    const int b = blockIdx.y, tid = threadIdx.x;
+    for (int e = tid; e < L; e += INV_T) ine[e] = in_edge[(int64_t)b * L + e];
+    int e0 = 0, e1 = 0;
+    if (tid < N) {
+        e0 = in_ptr[(int64_t)b * (N + 1) + tid];
+        e1 = in_ptr[(int64_t)b * (N + 1) + tid + 1];
+    }
+    constexpr int PF = INV_MAXL / 4 / INV_T;
+    float4 pre[PF];
+    auto fetch = [&](int p) {
+        const float4* src = reinterpret_cast<const float4*>(GPD + ((int64_t)b * Ctot * 3 + p) * L);
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int q = tid + i * INV_T;
+            pre[i] = q < L4 ? src[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    const int planes = Ctot * 3;
+    int p = blockIdx.x;
+    if (p < planes) fetch(p);
+    for (; p < planes; p += gridDim.x) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int q = tid + i * INV_T;
+            if (q < L4) reinterpret_cast<float4*>(plane)[q] = pre[i];
+        }
+        if (p + (int)gridDim.x < planes) fetch(p + gridDim.x);
+        __syncthreads();
+        if (tid < N) {
+            float s = 0.f;
+            const float4* r = reinterpret_cast<const float4*>(plane + tid * k);
+            for (int j = 0; j < (k >> 2); ++j) {
+                const float4 v = r[j];
+                s += (v.x + v.y) + (v.z + v.w);
+            }
+            float g = 0.f;
+            for (int e = e0; e < e1; ++e) g += plane[ine[e]];
+            gUV[((int64_t)b * 2 * planes + p) * N + tid] = g;
+            gUV[((int64_t)b * 2 * planes + planes + p) * N + tid] = s;
+        }
+    }
+}
+
 extern "C" size_t hpcs_edge_gather_bwd_workspace(int B, int C, int N) {
     if (B <= 0 || C <= 0 || N <= 0) return 64;
     const int CP = (C * 3 + 15) / 16 * 16;
@@ -1752,6 +1806,26 @@ extern "C" int hpcs_edge_grad_reduce(const float* GPD, const int64_t* idx, int B
     const int64_t L = (int64_t)N * k;
     const int CP = (Ctot * 3 + 15) / 16 * 16;
     const bool vec = (k % 4 == 0) && (((uintptr_t)GPD & 15u) == 0);
+    {   // inverse-graph path (see edge_gather_bwd_inv_kernel): no atomics, no scratch memset, GPD read once
+        static const bool off = getenv("HPCS_EDGE_BWD_ATOMIC") != nullptr;
+        const size_t ptr_bytes = ((size_t)B * (N + 1) * sizeof(int) + 255) & ~(size_t)255;
+        const size_t need = ptr_bytes + (size_t)B * L * sizeof(unsigned short);
+        if (!off && vec && N <= INV_T && L <= INV_MAXL && ws_bytes >= need) {
+            int* in_ptr = (int*)ws;
+            unsigned short* in_edge = (unsigned short*)((char*)ws + ptr_bytes);
+            hipLaunchKernelGGL(knn_inverse_kernel, dim3(B), dim3(INV_T), 0, ST, idx, N, k, in_ptr, in_edge);
+            HPCS_CHECK_LAUNCH();
+            (void)hipFuncSetAttribute((const void*)edge_grad_reduce_inv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      INV_MAXL * 6);
+            int groups = 256 / B;
+            if (groups < 1) groups = 1;
+            if (groups > Ctot * 3) groups = Ctot * 3;
+            hipLaunchKernelGGL(edge_grad_reduce_inv_kernel, dim3(groups, B), dim3(INV_T), (size_t)L * 6, ST, GPD, (const int*)in_ptr,
+                               (const unsigned short*)in_edge, Ctot, N, k, gUV);
+            HPCS_CHECK_LAUNCH();
+            return HPCS_OK;
+        }
+    }
     if (vec)
         hipLaunchKernelGGL((edge_segsum_kernel<true>), dim3(hpcs_cdiv(N, 64), Ctot, B), dim3(64), 0, ST, GPD, Ctot, N, k, gUV);
     else

@@ -105,6 +105,18 @@ class VNLinearLeakyReLU(nn.Module):                            # vn_layers.py:48
         return out
 
 
+    def forward_graph(self, feat, idx, pool_k=0):
+        """forward(get_graph_feature(feat, idx=idx), pool_k) with the same forward arithmetic and a point-level backward
+        (ops.VNGraphLayerFn): no edge-level data-gradient / weight-gradient GEMM, no scatter of an edge-sized gradient."""
+        if self.map_to_dir.weight.shape[0] == 1:
+            raise NotImplementedError("shared non-linearity is not used by the EdgeConv layers")
+        bn = self.batchnorm.bn
+        out = ops.vn_graph_layer(feat, idx, self.map_to_feat.weight, self.map_to_dir.weight, bn.weight, bn.bias,
+                                 bn.running_mean, bn.running_var, self.training, slope=self.negative_slope, pool_k=pool_k)
+        if self.training:
+            bump(bn)
+        return out
+
     def forward_edges(self, feat, idx, pool=False):
         """Equivalent to forward(get_graph_feature(feat, idx=idx)) [then mean over k if pool], computed from the
         point features: no [B,2C,3,N,k] edge tensor, and a channel GEMM k times smaller (ops.VNEdgeLayerFn)."""

@@ -68,6 +68,9 @@ class VN_DGCNN_partseg(nn.Module):
     # (VNLinearLeakyReLU.forward_edges); measured in round 1: same step time (cheaper GEMMs, dearer gathers and a
     # 2x larger scatter) and ~10x more fp32 noise from W_a x_nbr - W_a x_ctr cancellation -> not the default.
     edge_mode = "materialised"
+    # backward of the graph layers (conv1/3/5) reduced over the graph BEFORE the channel GEMMs (ops.VNGraphLayerFn); the
+    # forward arithmetic is that of "materialised" either way
+    point_level_backward = True
 
     def _edge_block(self, h, convs, pool):
         """kNN graph on h, then the block's VN layers; mean pooling is fused into the last layer."""
@@ -79,6 +82,15 @@ class VN_DGCNN_partseg(nn.Module):
                 e = convs[0].forward_edges(h, idx, pool=mean)
                 return e if mean else pool(e)
             e = convs[0].forward_edges(h, idx)
+            convs = convs[1:]
+        elif self.edge_mode == "materialised" and self.point_level_backward:
+            B, N = h.size(0), h.size(3)
+            idx = knn(h.reshape(B, -1, N), self.k)
+            if len(convs) == 1:
+                if mean:
+                    return convs[0].forward_graph(h, idx, pool_k=self.k)
+                return pool(convs[0].forward_graph(h, idx))
+            e = convs[0].forward_graph(h, idx)
             convs = convs[1:]
         else:
             e = get_graph_feature(h, k=self.k)

@@ -626,6 +626,101 @@ class VNEdgeLayerFn(torch.autograd.Function):
         return gfeat, None, gWf, gWd, red[Cout:].float(), red[:Cout].float(), None, None, None, None, None
 
 
+class VNGraphLayerFn(torch.autograd.Function):
+    """get_graph_feature + VNLinearLeakyReLU (+ mean over k), forward EXACTLY as the two separate ops (the edge tensor
+    [B,2C,3,N,k] is built and the channel mix runs on it: the reference's rounding sequence, difference before the mix),
+    backward at POINT level: the gradient of the stacked GEMM output is reduced over the graph first
+    (hpcs_edge_grad_reduce: gU by the transposed adjacency, gV over the k outgoing edges), then
+
+        g feat = Wa^T gU + (Wb - Wa)^T gV          dWa = gU feat^T - gV feat^T          dWb = gV feat^T
+
+    (W = [Wf;Wd] = [Wa | Wb], difference | centre columns).  This replaces the edge-level data-gradient GEMM (330 MB in,
+    330 MB out), the scatter of its output and the edge-level weight-gradient GEMM by GEMMs k times smaller, and the edge
+    tensor is not kept for backward.
+    """
+
+    @staticmethod
+    def forward(ctx, feat, idx, Wf, Wd, gamma, beta, rmean, rvar, training, slope, pool_k):
+        ctx.wparams = (Wf, Wd)
+        ctx.bnparams = (gamma, beta)
+        feat = _f32c(feat)
+        idx = idx.contiguous()
+        B, C, _, N = feat.shape
+        k = idx.shape[-1]
+        L = N * k
+        Cout, Cd = Wf.shape[0], Wd.shape[0]
+        Ctot = Cout + Cd
+        dev = feat.device
+        E = torch.empty(B, 2 * C, 3, N, k, device=dev, dtype=torch.float32)
+        call("hpcs_edge_gather_fwd", feat, idx, B, C, N, k, E)
+        WxP = PreparedW(Wf, Wd)
+        PD = gemm_WX(WxP, E, B, 2 * C, 3 * L)
+        del E
+        mean = torch.empty(Cout, device=dev)
+        rstd = torch.empty(Cout, device=dev)
+        sums = None
+        if training:
+            sums = _zeros64(2 * Cout, dev)
+            call("hpcs_vn_norm_stats", PD, B, Cout, Ctot, L, sums, 1)
+        call("hpcs_bn_finalize", sums, Cout, B * L, BN_EPS, BN_MOMENTUM, rmean, rvar, mean, rstd, 1 if training else 0)
+        out = torch.empty((B, Cout, 3, N) if pool_k else (B, Cout, 3, N, k), device=dev)
+        flags = VN_BN | VN_LRELU
+        call("hpcs_vn_apply_fwd", PD, mean, rstd, gamma, beta, B, Cout, Cd, L, pool_k, slope, flags, out)
+        ctx.save_for_backward(feat, idx, WxP.Wp, PD, mean, rstd, gamma, beta)
+        ctx.cfg = (B, C, N, k, Cout, Cd, pool_k, slope, flags, bool(training))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        feat, idx, Wp, PD, mean, rstd, gamma, beta = ctx.saved_tensors
+        B, C, N, k, Cout, Cd, pool_k, slope, flags, training = ctx.cfg
+        Ctot = Cout + Cd
+        L = N * k
+        g = _f32c(g)
+        dev = g.device
+        red = _zeros64(2 * Cout, dev)
+        call("hpcs_vn_bwd_reduce", PD, g, mean, rstd, gamma, beta, B, Cout, Cd, L, pool_k, slope, flags, red, 1)
+        GPD = torch.empty(B * Ctot * 3 * L, device=dev)
+        call("hpcs_vn_bwd_apply", PD, g, mean, rstd, gamma, beta, red, 1 if training else 0, B, Cout, Cd, L, pool_k, slope,
+             flags, GPD)
+        gUV = torch.empty(B, 2 * Ctot, 3, N, device=dev)
+        nbytes = call("hpcs_edge_grad_reduce_workspace", B, Ctot, N)
+        ws = torch.empty(nbytes // 4, device=dev)
+        call("hpcs_edge_grad_reduce", GPD, idx, B, Ctot, N, k, gUV, ws, nbytes)
+        del GPD
+        gfeat = gWf = gWd = None
+        W = Wp[:Ctot, :2 * C]                                            # [Wf;Wd] rows, (difference | centre) columns
+        if ctx.needs_input_grad[0]:
+            Wuv = torch.cat([W[:, :C], W[:, C:] - W[:, :C]], 0).contiguous()          # [2Ctot, C]
+            gfeat = gemm_WtG(Wuv, gUV, B, 2 * Ctot, 3 * N).view_as(feat)
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+            def weight_grads():
+                gWuv = gemm_GXt(gUV, feat, B, 2 * Ctot, C, 3 * N)                    # [2Ctot, C]
+                return torch.cat([gWuv[:Ctot] - gWuv[Ctot:], gWuv[Ctot:]], dim=1)     # [Ctot, 2C]
+
+            Wf_, Wd_ = ctx.wparams
+            sink_f = _grad_sink((Wf_, ...)) if ctx.needs_input_grad[2] else None
+            sink_d = _grad_sink((Wd_, ...)) if ctx.needs_input_grad[3] else None
+            if (sink_f is not None or not ctx.needs_input_grad[2]) and (sink_d is not None or not ctx.needs_input_grad[3]):
+                def work():
+                    gWcat = weight_grads()
+                    if sink_f is not None:
+                        sink_f.add_(gWcat[:Cout])
+                    if sink_d is not None:
+                        sink_d.add_(gWcat[Cout:])
+                _on_side_stream(work, (gUV, feat))
+            else:
+                gWcat = weight_grads()
+                gWf, gWd = gWcat[:Cout], gWcat[Cout:]
+        ggamma, gbeta = _bn_grads(ctx.bnparams, red, Cout, ctx.needs_input_grad[4], ctx.needs_input_grad[5])
+        return gfeat, None, gWf, gWd, ggamma, gbeta, None, None, None, None, None
+
+
+def vn_graph_layer(feat, idx, Wf, Wd, gamma, beta, rmean, rvar, training, slope=0.2, pool_k=0):
+    _need_cuda(feat, idx, Wf)
+    return VNGraphLayerFn.apply(feat, idx, Wf, Wd, gamma, beta, rmean, rvar, training, slope, pool_k)
+
+
 def vn_edge_layer(feat, idx, Wf, Wd, gamma, beta, rmean, rvar, training, slope=0.2, pool=False):
     _need_cuda(feat, idx, Wf)
     return VNEdgeLayerFn.apply(feat, idx, Wf, Wd, gamma, beta, rmean, rvar, training, slope, pool)

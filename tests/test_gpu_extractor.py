@@ -389,6 +389,34 @@ def test_edge_layer_equals_gather_then_layer(C, pool):
         relclose(a, b, 2e-5)
 
 
+@pytest.mark.parametrize("C,pool,N,k", [(1, False, 96, 8), (21, False, 96, 8), (21, True, 96, 8), (21, True, 1024, 20)])
+def test_graph_layer_point_level_backward(C, pool, N, k):
+    """forward_graph: forward BIT-identical to the layer on the materialised graph feature; the point-level backward
+    (graph reduction first, then k-times smaller GEMMs) gives the same gradients up to fp32 reassociation."""
+    from hpcs_amd.nn.dgcnn.utils.vn_layers import VNLinearLeakyReLU
+    from hpcs_amd.nn.dgcnn.utils.vn_dgcnn_util import get_graph_feature
+    B = 3
+    feat = det_normalish((B, C, 3, N), 810 + C)
+    idx = det_int((B, N, k), 811, N).to(dev)
+    res = []
+    for mode in ("graph", "materialised"):
+        m = load(VNLinearLeakyReLU(2 * C, 21), 812)
+        m.train()
+        fg = feat.to(dev).requires_grad_(True)
+        if mode == "graph":
+            y = m.forward_graph(fg, idx, pool_k=k if pool else 0)
+        else:
+            y = m(get_graph_feature(fg, k=k, idx=idx), pool_k=k if pool else 0)
+        w = det_uniform(tuple(y.shape), 813).to(dev)
+        (y * w).sum().backward()
+        res.append((y.detach(), fg.grad, m.map_to_feat.weight.grad, m.map_to_dir.weight.grad, m.batchnorm.bn.weight.grad,
+                    m.batchnorm.bn.bias.grad, m.batchnorm.bn.running_var.clone()))
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.equal(res[0][6], res[1][6])
+    for a, b in zip(res[0][1:6], res[1][1:6]):
+        relclose(a, b, 5e-5)
+
+
 def test_extractor_gather_mode_close_to_materialised():
     """The opt-in edge_mode='gather' path computes the same network (up to fp32 reassociation noise)."""
     from hpcs_amd.nn.dgcnn import VN_DGCNN_partseg
