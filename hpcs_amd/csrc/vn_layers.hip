@@ -1333,6 +1333,8 @@ extern "C" int hpcs_edge_gather_fwd(const float* x, const int64_t* idx, int B, i
     return HPCS_OK;
 }
 
+namespace {
+
 // ---- backward of get_graph_feature through the INVERSE graph (N <= 1024, N*k <= 20480: the BASELINE geometry) ------------
 // The scatter-add over idx is a gather over the transposed adjacency: gx[m] = sum over the edges e = (n, j) with
 // idx[n, j] = m of g_diff[e], plus the centre part sum_j (g_ctr[m, j] - g_diff[m, j]).  One workgroup per cloud builds the
@@ -1342,116 +1344,254 @@ extern "C" int hpcs_edge_gather_fwd(const float* x, const int64_t* idx, int B, i
 // `gout` read once.  Replaces centre pass + memset + atomic scatter + fold (57 + 10 + 160-200 + 15 us per 330 MB layer).
 constexpr int INV_T = 1024;
 constexpr int INV_MAXL = 20480;
-__global__ __launch_bounds__(INV_T) void knn_inverse_kernel(const int64_t* __restrict__ idx, int N, int k,
-                                                            int* __restrict__ in_ptr, unsigned short* __restrict__ in_edge) {
-    __shared__ int hist[INV_T + 1];
-    __shared__ int cursor[INV_T];
+constexpr int INV_HUB = 64;                          // in-degree above which a point is reduced by a whole wave
+constexpr int INV_MAXHUB = INV_MAXL / (INV_HUB + 1) + 1;
+// A feature-space kNN graph can have HUBS (early in training thousands of points share a nearest neighbour): a
+// thread-per-point loop over a 5000-long list held the whole workgroup for 540 us.  Points with more than INV_HUB incoming
+// edges are therefore listed separately and summed by one wave each (lanes stride the list, shuffle tree: still a fixed
+// order).
+struct InvGraph {                                    // per-call scratch inside the caller's workspace
+    int* in_ptr;                                     // [B][N+1]
+    unsigned short* in_edge;                         // [B][L]  edge ids grouped by target, ascending inside a group
+    int* hub_cnt;                                    // [B]
+    unsigned short* hub_ids;                         // [B][INV_MAXHUB]
+    short* hub_slot;                                 // [B][N]  -1 or the point's position in hub_ids
+    size_t bytes;
+};
+InvGraph inv_graph_layout(void* ws, int B, int N, int64_t L) {
+    InvGraph g;
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t r = o; o += (n + 255) & ~(size_t)255; return (char*)ws + r; };
+    g.in_ptr = (int*)take((size_t)B * (N + 1) * sizeof(int));
+    g.in_edge = (unsigned short*)take((size_t)B * L * sizeof(unsigned short));
+    g.hub_cnt = (int*)take((size_t)B * sizeof(int));
+    g.hub_ids = (unsigned short*)take((size_t)B * INV_MAXHUB * sizeof(unsigned short));
+    g.hub_slot = (short*)take((size_t)B * N * sizeof(short));
+    g.bytes = o;
+    return g;
+}
+
+__global__ __launch_bounds__(INV_T) void knn_inverse_kernel(const int64_t* __restrict__ idx, int N, int k, int* __restrict__ in_ptr,
+                                                            unsigned short* __restrict__ in_edge, int* __restrict__ hub_cnt,
+                                                            unsigned short* __restrict__ hub_ids, short* __restrict__ hub_slot) {
+    // Counting sort of the edges by target with every list ascending in the edge id (= a fixed summation order later):
+    //   short lists: slots handed out by LDS atomics, then a per-thread insertion sort of <= INV_HUB entries;
+    //   hub lists (thousands of entries): placed STABLY, 1024 edges at a time -- an edge's slot is the list cursor + the
+    //   same-hub edges of lower waves (per-wave counters) + the same-hub lanes below it in its wave (ballot/popcount).
+    __shared__ int cur[INV_T];                       // in-degree histogram, then the running list cursors
     __shared__ int wsum[INV_T / 64];
     __shared__ unsigned short ine[INV_MAXL];
+    __shared__ unsigned short hubs[INV_MAXHUB];
+    __shared__ short slot_of[INV_T];                 // hub slot of a point or -1
+    __shared__ unsigned char wcount[INV_T / 64][INV_MAXHUB];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int L = N * k;
     const int64_t* ib = idx + (int64_t)b * L;
-    hist[tid] = 0;
-    __syncthreads();
-    for (int e = tid; e < L; e += INV_T) {
-        const int m = (int)ib[e];
-        if ((unsigned)m < (unsigned)N) atomicAdd(&hist[m], 1);        // kNN indices are cloud-local; anything else is dropped
+    cur[tid] = 0;
+    for (int i = tid; i < (INV_T / 64) * INV_MAXHUB; i += INV_T) (&wcount[0][0])[i] = 0;
+    constexpr int CH = INV_MAXL / INV_T;             // edges per thread: all targets are fetched once, up front
+    short tgt[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int e = c * INV_T + tid;
+        const int m = e < L ? (int)ib[e] : -1;
+        tgt[c] = (unsigned)m < (unsigned)N ? (short)m : (short)-1;    // kNN indices are cloud-local; anything else is dropped
     }
     __syncthreads();
-    // exclusive scan over the N (<= 1024) counts
-    const int cnt = tid < N ? hist[tid] : 0;
-    int incl = cnt;
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+        if (tgt[c] >= 0) atomicAdd(&cur[tgt[c]], 1);
+    __syncthreads();
+    // exclusive scans over the N (<= 1024) counts: list starts and hub slots
+    const int cnt = tid < N ? cur[tid] : 0;
+    const int is_hub = cnt > INV_HUB ? 1 : 0;
+    int incl = cnt, hincl = is_hub;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += t;
+        const int t = __shfl_up(incl, o, 64), th = __shfl_up(hincl, o, 64);
+        if (lane >= o) { incl += t; hincl += th; }
     }
-    if (lane == 63) wsum[wv] = incl;
+    if (lane == 63) wsum[wv] = incl | (hincl << 20);                   // counts < 2^20, hubs < 2^11
     __syncthreads();
-    int base = 0;
-    for (int w = 0; w < wv; ++w) base += wsum[w];
+    int base = 0, hbase = 0, nh = 0;
+    for (int w = 0; w < INV_T / 64; ++w) {
+        const int v = wsum[w];
+        if (w < wv) { base += v & 0xfffff; hbase += v >> 20; }
+        nh += v >> 20;
+    }
     const int start = base + incl - cnt;
-    cursor[tid] = start;
-    __syncthreads();
-    for (int e = tid; e < L; e += INV_T) {
-        const int m = (int)ib[e];
-        if ((unsigned)m < (unsigned)N) ine[atomicAdd(&cursor[m], 1)] = (unsigned short)e;
+    const int slot = hbase + hincl - is_hub;
+    cur[tid] = start;
+    slot_of[tid] = is_hub ? (short)slot : (short)-1;
+    if (is_hub) hubs[slot] = (unsigned short)tid;
+    if (tid < N) {
+        in_ptr[(int64_t)b * (N + 1) + tid] = start;
+        if (tid == N - 1) in_ptr[(int64_t)b * (N + 1) + N] = start + cnt;
+        hub_slot[(int64_t)b * N + tid] = is_hub ? (short)slot : (short)-1;
     }
     __syncthreads();
-    if (tid < N) {                                   // fixed summation order: every list ascending in the edge id
+    // short lists
+    short hs[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        hs[c] = tgt[c] >= 0 ? slot_of[tgt[c]] : (short)-1;
+        if (tgt[c] >= 0 && hs[c] < 0) ine[atomicAdd(&cur[tgt[c]], 1)] = (unsigned short)(c * INV_T + tid);
+    }
+    __syncthreads();
+    if (tid < N && !is_hub)
         for (int i = start + 1; i < start + cnt; ++i) {
             const unsigned short v = ine[i];
             int j = i - 1;
             while (j >= start && ine[j] > v) { ine[j + 1] = ine[j]; --j; }
             ine[j + 1] = v;
         }
-        in_ptr[(int64_t)b * (N + 1) + tid] = start;
-        if (tid == N - 1) in_ptr[(int64_t)b * (N + 1) + N] = start + cnt;
+    // hub lists (nh is uniform)
+    if (nh > 0) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            if (c * INV_T >= L) break;               // uniform
+            const int h = hs[c];
+            int rank = 0, tot = 0;
+            unsigned long long todo = __ballot(h >= 0);
+            while (todo) {                           // one round per distinct hub among the wave's 64 edges
+                const int lead = __ffsll((long long)todo) - 1;
+                const int hl = __builtin_amdgcn_readlane(h, lead);
+                const unsigned long long mask = __ballot(h == hl);
+                if (h == hl) {
+                    rank = __popcll(mask & ((1ull << lane) - 1ull));
+                    tot = __popcll(mask);
+                }
+                todo &= ~mask;
+            }
+            const bool leader = h >= 0 && rank == 0;
+            if (leader) wcount[wv][h] = (unsigned char)tot;           // tot <= 64
+            __syncthreads();
+            if (h >= 0) {
+                int off = 0;
+                for (int w = 0; w < wv; ++w) off += wcount[w][h];
+                ine[cur[tgt[c]] + off + rank] = (unsigned short)(c * INV_T + tid);
+            }
+            __syncthreads();
+            if (leader) {
+                atomicAdd(&cur[tgt[c]], tot);
+                wcount[wv][h] = 0;
+            }
+            __syncthreads();
+        }
     }
     __syncthreads();
     for (int e = tid; e < L; e += INV_T) in_edge[(int64_t)b * L + e] = ine[e];
+    for (int h = tid; h < nh; h += INV_T) hub_ids[(int64_t)b * INV_MAXHUB + h] = hubs[h];
+    if (tid == 0) hub_cnt[b] = nh;
 }
+
+// LDS image shared by the two reduction kernels: one plane of N*k floats, the transposed edge list and the hub tables.
+struct InvLds {
+    float* plane;                // [L]
+    unsigned short* ine;         // [L]
+    float* hub_g;                // [INV_MAXHUB]
+    int* hub_e0;                 // [INV_MAXHUB]
+    int* hub_e1;                 // [INV_MAXHUB]
+};
+constexpr size_t INV_LDS_BYTES = (size_t)INV_MAXL * 6 + (size_t)INV_MAXHUB * 12 + 64;
+__device__ __forceinline__ InvLds inv_lds_layout(float4* raw, int L) {
+    InvLds l;
+    l.plane = reinterpret_cast<float*>(raw);
+    l.hub_g = l.plane + L;
+    l.hub_e0 = reinterpret_cast<int*>(l.hub_g + INV_MAXHUB);
+    l.hub_e1 = l.hub_e0 + INV_MAXHUB;
+    l.ine = reinterpret_cast<unsigned short*>(l.hub_e1 + INV_MAXHUB);
+    return l;
+}
+struct InvOwn { int e0, e1, hs, nh; };
+__device__ __forceinline__ InvOwn inv_load_graph(const InvLds& l, const int* in_ptr, const unsigned short* in_edge,
+                                                 const int* hub_cnt, const short* hub_slot, int b, int N, int L) {
+    const int tid = threadIdx.x;
+    for (int e = tid; e < L; e += INV_T) l.ine[e] = in_edge[(int64_t)b * L + e];
+    InvOwn o{0, 0, -1, hub_cnt[b]};
+    if (tid < N) {
+        o.e0 = in_ptr[(int64_t)b * (N + 1) + tid];
+        o.e1 = in_ptr[(int64_t)b * (N + 1) + tid + 1];
+        o.hs = hub_slot[(int64_t)b * N + tid];
+        if (o.hs >= 0) { l.hub_e0[o.hs] = o.e0; l.hub_e1[o.hs] = o.e1; }
+    }
+    return o;
+}
+// sum of the staged plane over the incoming edges of this thread's point; hubs are summed by whole waves into hub_g and
+// picked up after the barrier this function contains
+__device__ __forceinline__ float inv_gather(const InvLds& l, const InvOwn& o) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int h = wv; h < o.nh; h += INV_T / 64) {
+        float acc = 0.f;
+        for (int e = l.hub_e0[h] + lane; e < l.hub_e1[h]; e += 64) acc += l.plane[l.ine[e]];
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) acc += __shfl_xor(acc, s, 64);
+        if (lane == 0) l.hub_g[h] = acc;
+    }
+    float g = 0.f;
+    if (o.hs < 0)
+        for (int e = o.e0; e < o.e1; ++e) g += l.plane[l.ine[e]];
+    if (o.nh > 0) {                                  // uniform across the workgroup
+        __syncthreads();
+        if (o.hs >= 0) g = l.hub_g[o.hs];
+    }
+    return g;
+}
+__device__ __forceinline__ float inv_own_sum(const float* plane, int N, int k) {       // sum_j plane[tid*k + j], k % 4 == 0
+    float s = 0.f;
+    if ((int)threadIdx.x < N) {
+        const float4* r = reinterpret_cast<const float4*>(plane + threadIdx.x * k);
+        for (int j = 0; j < (k >> 2); ++j) {
+            const float4 v = r[j];
+            s += (v.x + v.y) + (v.z + v.w);
+        }
+    }
+    return s;
+}
+constexpr int INV_PF = INV_MAXL / 4 / INV_T;         // float4 prefetch registers per thread (5)
 
 // grid (groups, B): the workgroup walks planes p = group, group + groups, ... of cloud b (p = c*3 + a).
 __global__ __launch_bounds__(INV_T) void edge_gather_bwd_inv_kernel(const float* __restrict__ gout, const int* __restrict__ in_ptr,
-                                                                    const unsigned short* __restrict__ in_edge, int C, int N,
-                                                                    int k, float* __restrict__ gx) {
+                                                                    const unsigned short* __restrict__ in_edge,
+                                                                    const int* __restrict__ hub_cnt, const short* __restrict__ hub_slot,
+                                                                    int C, int N, int k, float* __restrict__ gx) {
     extern __shared__ float4 inv_lds[];
     const int L = N * k, L4 = L >> 2;                // host guarantees L % 4 == 0
-    float* plane = reinterpret_cast<float*>(inv_lds);                                   // [L]
-    unsigned short* ine = reinterpret_cast<unsigned short*>(plane + L);                 // [L]
+    const InvLds l = inv_lds_layout(inv_lds, L);
     const int b = blockIdx.y, tid = threadIdx.x;
-    for (int e = tid; e < L; e += INV_T) ine[e] = in_edge[(int64_t)b * L + e];
-    int e0 = 0, e1 = 0;
-    if (tid < N) {
-        e0 = in_ptr[(int64_t)b * (N + 1) + tid];
-        e1 = in_ptr[(int64_t)b * (N + 1) + tid + 1];
-    }
-    constexpr int PF = INV_MAXL / 4 / INV_T;         // float4 prefetch registers per thread (5)
-    float4 pre[PF];
+    const InvOwn own = inv_load_graph(l, in_ptr, in_edge, hub_cnt, hub_slot, b, N, L);
+    float4 pre[INV_PF];
     auto fetch = [&](int p, int half) {              // half 0: difference channels [0,C), 1: centre channels [C,2C)
         const int c = p / 3, a = p % 3;
         const float4* src = reinterpret_cast<const float4*>(gout + (((int64_t)b * 2 * C + half * C + c) * 3 + a) * L);
 #pragma unroll
-        for (int i = 0; i < PF; ++i) {
+        for (int i = 0; i < INV_PF; ++i) {
             const int q = tid + i * INV_T;
             pre[i] = q < L4 ? src[q] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto stash = [&]() {
 #pragma unroll
-        for (int i = 0; i < PF; ++i) {
+        for (int i = 0; i < INV_PF; ++i) {
             const int q = tid + i * INV_T;
-            if (q < L4) reinterpret_cast<float4*>(plane)[q] = pre[i];
+            if (q < L4) reinterpret_cast<float4*>(l.plane)[q] = pre[i];
         }
-    };
-    auto own_sum = [&]() {                           // sum_j plane[tid*k + j]
-        float s = 0.f;
-        if (tid < N) {
-            const float4* r = reinterpret_cast<const float4*>(plane + tid * k);       // k % 4 == 0
-            for (int j = 0; j < (k >> 2); ++j) {
-                const float4 v = r[j];
-                s += (v.x + v.y) + (v.z + v.w);
-            }
-        }
-        return s;
     };
     const int planes = C * 3;
     int p = blockIdx.x;
     if (p < planes) fetch(p, 1);
     for (; p < planes; p += gridDim.x) {
-        __syncthreads();                             // previous plane fully consumed
+        __syncthreads();                             // previous plane fully consumed (and the graph tables are in place)
         stash();                                     // centre plane
         fetch(p, 0);
         __syncthreads();
-        float s = own_sum();
+        float s = inv_own_sum(l.plane, N, k);
         __syncthreads();
         stash();                                     // difference plane
         if (p + (int)gridDim.x < planes) fetch(p + gridDim.x, 1);
         __syncthreads();
-        s -= own_sum();
-        float g = 0.f;
-        for (int e = e0; e < e1; ++e) g += plane[ine[e]];
+        s -= inv_own_sum(l.plane, N, k);
+        const float g = inv_gather(l, own);
         if (tid < N) gx[((int64_t)b * planes + p) * N + tid] = g + s;
     }
 }
@@ -1460,25 +1600,19 @@ __global__ __launch_bounds__(INV_T) void edge_gather_bwd_inv_kernel(const float*
 // gU[m] = sum over the edges pointing at m (channels [0,Ctot)) and gV[n] = sum over the k edges leaving n (channels
 // [Ctot,2Ctot)).  One staged plane serves both sums.
 __global__ __launch_bounds__(INV_T) void edge_grad_reduce_inv_kernel(const float* __restrict__ GPD, const int* __restrict__ in_ptr,
-                                                                     const unsigned short* __restrict__ in_edge, int Ctot, int N,
-                                                                     int k, float* __restrict__ gUV) {
+                                                                     const unsigned short* __restrict__ in_edge,
+                                                                     const int* __restrict__ hub_cnt, const short* __restrict__ hub_slot,
+                                                                     int Ctot, int N, int k, float* __restrict__ gUV) {
     extern __shared__ float4 inv_lds[];
     const int L = N * k, L4 = L >> 2;
-    float* plane = reinterpret_cast<float*>(inv_lds);
-    unsigned short* ine = reinterpret_cast<unsigned short*>(plane + L);
+    const InvLds l = inv_lds_layout(inv_lds, L);
     const int b = blockIdx.y, tid = threadIdx.x;
-    for (int e = tid; e < L; e += INV_T) ine[e] = in_edge[(int64_t)b * L + e];
-    int e0 = 0, e1 = 0;
-    if (tid < N) {
-        e0 = in_ptr[(int64_t)b * (N + 1) + tid];
-        e1 = in_ptr[(int64_t)b * (N + 1) + tid + 1];
-    }
-    constexpr int PF = INV_MAXL / 4 / INV_T;
-    float4 pre[PF];
+    const InvOwn own = inv_load_graph(l, in_ptr, in_edge, hub_cnt, hub_slot, b, N, L);
+    float4 pre[INV_PF];
     auto fetch = [&](int p) {
         const float4* src = reinterpret_cast<const float4*>(GPD + ((int64_t)b * Ctot * 3 + p) * L);
 #pragma unroll
-        for (int i = 0; i < PF; ++i) {
+        for (int i = 0; i < INV_PF; ++i) {
             const int q = tid + i * INV_T;
             pre[i] = q < L4 ? src[q] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -1489,26 +1623,40 @@ __global__ __launch_bounds__(INV_T) void edge_grad_reduce_inv_kernel(const float
     for (; p < planes; p += gridDim.x) {
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < PF; ++i) {
+        for (int i = 0; i < INV_PF; ++i) {
             const int q = tid + i * INV_T;
-            if (q < L4) reinterpret_cast<float4*>(plane)[q] = pre[i];
+            if (q < L4) reinterpret_cast<float4*>(l.plane)[q] = pre[i];
         }
         if (p + (int)gridDim.x < planes) fetch(p + gridDim.x);
         __syncthreads();
+        const float s = inv_own_sum(l.plane, N, k);
+        const float g = inv_gather(l, own);
         if (tid < N) {
-            float s = 0.f;
-            const float4* r = reinterpret_cast<const float4*>(plane + tid * k);
-            for (int j = 0; j < (k >> 2); ++j) {
-                const float4 v = r[j];
-                s += (v.x + v.y) + (v.z + v.w);
-            }
-            float g = 0.f;
-            for (int e = e0; e < e1; ++e) g += plane[ine[e]];
             gUV[((int64_t)b * 2 * planes + p) * N + tid] = g;
             gUV[((int64_t)b * 2 * planes + planes + p) * N + tid] = s;
         }
     }
 }
+
+// builds the transposed graph in `ws` and returns its tables; false when the geometry does not fit the LDS plan
+bool inv_graph_build(const int64_t* idx, int B, int N, int k, bool vec, void* ws, size_t ws_bytes, hipStream_t st, InvGraph* out) {
+    static const bool off = getenv("HPCS_EDGE_BWD_ATOMIC") != nullptr;
+    const int64_t L = (int64_t)N * k;
+    if (off || !vec || N > INV_T || L > INV_MAXL || (L % 4) != 0) return false;
+    const InvGraph g = inv_graph_layout(ws, B, N, L);
+    if (ws_bytes < g.bytes) return false;
+    hipLaunchKernelGGL(knn_inverse_kernel, dim3(B), dim3(INV_T), 0, st, idx, N, k, g.in_ptr, g.in_edge, g.hub_cnt, g.hub_ids,
+                       g.hub_slot);
+    *out = g;
+    return true;
+}
+int inv_groups(int B, int planes) {
+    int groups = 256 / B;                            // ~one workgroup per CU; each walks planes/groups planes of its cloud
+    if (groups < 1) groups = 1;
+    return groups > planes ? planes : groups;
+}
+
+}  // namespace
 
 extern "C" size_t hpcs_edge_gather_bwd_workspace(int B, int C, int N) {
     if (B <= 0 || C <= 0 || N <= 0) return 64;
@@ -1526,22 +1674,14 @@ extern "C" int hpcs_edge_gather_bwd(const float* gout, const int64_t* idx, int B
     const int CP = (C * 3 + 15) / 16 * 16;
     const bool vec = (k % 4 == 0) && (((uintptr_t)gout & 15u) == 0);
     {   // inverse-graph path: the whole cloud's plane fits one workgroup's LDS
-        static const bool off = getenv("HPCS_EDGE_BWD_ATOMIC") != nullptr;
-        const size_t ptr_bytes = ((size_t)B * (N + 1) * sizeof(int) + 255) & ~(size_t)255;
-        const size_t need = ptr_bytes + (size_t)B * L * sizeof(unsigned short);
-        if (!off && vec && N <= INV_T && L <= INV_MAXL && (L % 4) == 0 && ws_bytes >= need) {
-            int* in_ptr = (int*)ws;
-            unsigned short* in_edge = (unsigned short*)((char*)ws + ptr_bytes);
-            hipLaunchKernelGGL(knn_inverse_kernel, dim3(B), dim3(INV_T), 0, ST, idx, N, k, in_ptr, in_edge);
+        InvGraph ig;
+        if (inv_graph_build(idx, B, N, k, vec, ws, ws_bytes, ST, &ig)) {
             HPCS_CHECK_LAUNCH();
-            const size_t lds = (size_t)L * (sizeof(float) + sizeof(unsigned short));
             (void)hipFuncSetAttribute((const void*)edge_gather_bwd_inv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      INV_MAXL * 6);
-            int groups = 256 / B;                    // ~one workgroup per CU; each walks planes/groups planes of its cloud
-            if (groups < 1) groups = 1;
-            if (groups > C * 3) groups = C * 3;
-            hipLaunchKernelGGL(edge_gather_bwd_inv_kernel, dim3(groups, B), dim3(INV_T), lds, ST, gout, (const int*)in_ptr,
-                               (const unsigned short*)in_edge, C, N, k, gx);
+                                      (int)INV_LDS_BYTES);
+            hipLaunchKernelGGL(edge_gather_bwd_inv_kernel, dim3(inv_groups(B, C * 3), B), dim3(INV_T), INV_LDS_BYTES, ST, gout,
+                               (const int*)ig.in_ptr, (const unsigned short*)ig.in_edge, (const int*)ig.hub_cnt,
+                               (const short*)ig.hub_slot, C, N, k, gx);
             HPCS_CHECK_LAUNCH();
             return HPCS_OK;
         }
@@ -1807,21 +1947,14 @@ extern "C" int hpcs_edge_grad_reduce(const float* GPD, const int64_t* idx, int B
     const int CP = (Ctot * 3 + 15) / 16 * 16;
     const bool vec = (k % 4 == 0) && (((uintptr_t)GPD & 15u) == 0);
     {   // inverse-graph path (see edge_gather_bwd_inv_kernel): no atomics, no scratch memset, GPD read once
-        static const bool off = getenv("HPCS_EDGE_BWD_ATOMIC") != nullptr;
-        const size_t ptr_bytes = ((size_t)B * (N + 1) * sizeof(int) + 255) & ~(size_t)255;
-        const size_t need = ptr_bytes + (size_t)B * L * sizeof(unsigned short);
-        if (!off && vec && N <= INV_T && L <= INV_MAXL && ws_bytes >= need) {
-            int* in_ptr = (int*)ws;
-            unsigned short* in_edge = (unsigned short*)((char*)ws + ptr_bytes);
-            hipLaunchKernelGGL(knn_inverse_kernel, dim3(B), dim3(INV_T), 0, ST, idx, N, k, in_ptr, in_edge);
+        InvGraph ig;
+        if (inv_graph_build(idx, B, N, k, vec, ws, ws_bytes, ST, &ig)) {
             HPCS_CHECK_LAUNCH();
             (void)hipFuncSetAttribute((const void*)edge_grad_reduce_inv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      INV_MAXL * 6);
-            int groups = 256 / B;
-            if (groups < 1) groups = 1;
-            if (groups > Ctot * 3) groups = Ctot * 3;
-            hipLaunchKernelGGL(edge_grad_reduce_inv_kernel, dim3(groups, B), dim3(INV_T), (size_t)L * 6, ST, GPD, (const int*)in_ptr,
-                               (const unsigned short*)in_edge, Ctot, N, k, gUV);
+                                      (int)INV_LDS_BYTES);
+            hipLaunchKernelGGL(edge_grad_reduce_inv_kernel, dim3(inv_groups(B, Ctot * 3), B), dim3(INV_T), INV_LDS_BYTES, ST, GPD,
+                               (const int*)ig.in_ptr, (const unsigned short*)ig.in_edge, (const int*)ig.hub_cnt,
+                               (const short*)ig.hub_slot, Ctot, N, k, gUV);
             HPCS_CHECK_LAUNCH();
             return HPCS_OK;
         }
