@@ -47,8 +47,10 @@ int hpcs_knn(const float* x, int B, int D, int N, int k, int64_t* idx, void* ws,
 
 /* ---- a2: get_graph_feature  hpcs/nn/dgcnn/utils/vn_dgcnn_util.py:13-41 ----------------------
  * x [B,C,3,N], idx [B,N,k] (cloud-local) -> out [B,2C,3,N,k] = (x[nbr]-x[ctr], x[ctr]).
- * bwd: gx [B,C,3,N] is overwritten; the neighbour scatter-add goes through a point-major scratch
- * (hpcs_edge_gather_bwd_workspace bytes) with row-contiguous fp32 atomics. */
+ * bwd: gx [B,C,3,N] is overwritten.  N <= 1024, N*k <= 20480, k % 4 == 0: the scatter-add runs as a GATHER over the
+ * transposed graph, which is built in `ws` on every call (no atomics, fixed summation order, bit-reproducible);
+ * otherwise the neighbour part goes through a point-major scratch with row-contiguous fp32 atomics.
+ * `ws`: hpcs_edge_gather_bwd_workspace bytes (covers both). */
 int hpcs_edge_gather_fwd(const float* x, const int64_t* idx, int B, int C, int N, int k, float* out,
                          hpcs_stream_t stream);
 size_t hpcs_edge_gather_bwd_workspace(int B, int C, int N);
@@ -121,7 +123,10 @@ int hpcs_vn_bwd_fused(const float* PD, const float* gout, const float* X, const 
  * U = W_a F (channels [0,Ctot)) and V = (W_b - W_a) F (channels [Ctot,2Ctot)) from ONE k-times-smaller GEMM; the
  * kernels form PD[b,ch,:,n*k+j] = U[b,ch,:,idx[b,n,j]] + V[b,ch,:,n] on the fly.  Same semantics as the
  * materialised entry points above with L = N*k; pool != 0 fuses the mean over the k neighbours.
- * edge_grad_reduce: GPD [B,Ctot,3,N*k] -> gUV (gU = scatter-add over idx, gV = sum over k). */
+ * edge_grad_reduce: GPD [B,Ctot,3,N*k] -> gUV (gU = scatter-add over idx, gV = sum over k); also the first step of the
+ * point-level backward of the MATERIALISED graph layers (reduce over the graph, then k-times smaller GEMMs).  Runs as a
+ * gather over the transposed graph (built in `ws` per call; hub points are summed by whole waves) when N <= 1024,
+ * N*k <= 20480 and k % 4 == 0, else with row-contiguous fp32 atomics. */
 int hpcs_vn_edge_norm_stats(const float* UV, const int64_t* idx, int B, int Cout, int Ctot, int N, int k,
                             double* sums, int sums_zeroed, hpcs_stream_t stream);
 int hpcs_vn_edge_apply_fwd(const float* UV, const int64_t* idx, const float* mean, const float* rstd,
