@@ -1358,6 +1358,7 @@ struct InvGraph {                                    // per-call scratch inside 
     short* hub_slot;                                 // [B][N]  -1 or the point's position in hub_ids
     size_t bytes;
 };
+constexpr int INV_MAXSLAB = 4;                       // slabs per cloud (N*k <= 81920)
 InvGraph inv_graph_layout(void* ws, int B, int N, int64_t L) {
     InvGraph g;
     size_t o = 0;
@@ -1371,23 +1372,31 @@ InvGraph inv_graph_layout(void* ws, int B, int N, int64_t L) {
     return g;
 }
 
-__global__ __launch_bounds__(INV_T) void knn_inverse_kernel(const int64_t* __restrict__ idx, int N, int k, int* __restrict__ in_ptr,
-                                                            unsigned short* __restrict__ in_edge, int* __restrict__ hub_cnt,
-                                                            unsigned short* __restrict__ hub_ids, short* __restrict__ hub_slot) {
+// One workgroup per (cloud, slab).  A slab is a run of N/S source points = Ls = N*k/S consecutive edges (S = 1 for
+// N*k <= INV_MAXL; the N = 2048 / k = 40 geometry uses S = 4 slabs of 512 points): every slab gets its own transposed
+// graph over ALL N targets, with slab-local edge ids, so that the reduction can stage one slab of a plane in LDS at a time.
+// NT = targets per thread (N <= NT * 1024).
+template <int NT>
+__global__ __launch_bounds__(INV_T) void knn_inverse_kernel(const int64_t* __restrict__ idx, int N, int Ls, int S,
+                                                            int* __restrict__ in_ptr, unsigned short* __restrict__ in_edge,
+                                                            int* __restrict__ hub_cnt, unsigned short* __restrict__ hub_ids,
+                                                            short* __restrict__ hub_slot) {
     // Counting sort of the edges by target with every list ascending in the edge id (= a fixed summation order later):
     //   short lists: slots handed out by LDS atomics, then a per-thread insertion sort of <= INV_HUB entries;
     //   hub lists (thousands of entries): placed STABLY, 1024 edges at a time -- an edge's slot is the list cursor + the
     //   same-hub edges of lower waves (per-wave counters) + the same-hub lanes below it in its wave (ballot/popcount).
-    __shared__ int cur[INV_T];                       // in-degree histogram, then the running list cursors
+    __shared__ int cur[NT * INV_T];                  // in-degree histogram, then the running list cursors
     __shared__ int wsum[INV_T / 64];
     __shared__ unsigned short ine[INV_MAXL];
     __shared__ unsigned short hubs[INV_MAXHUB];
-    __shared__ short slot_of[INV_T];                 // hub slot of a point or -1
+    __shared__ short slot_of[NT * INV_T];            // hub slot of a point or -1
     __shared__ unsigned char wcount[INV_T / 64][INV_MAXHUB];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int L = N * k;
-    const int64_t* ib = idx + (int64_t)b * L;
-    cur[tid] = 0;
+    const int bs = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int L = Ls;
+    const int64_t* ib = idx + (int64_t)bs * Ls;      // clouds and slabs are consecutive runs of the edge array
+    (void)S;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) cur[tid + j * INV_T] = 0;
     for (int i = tid; i < (INV_T / 64) * INV_MAXHUB; i += INV_T) (&wcount[0][0])[i] = 0;
     constexpr int CH = INV_MAXL / INV_T;             // edges per thread: all targets are fetched once, up front
     short tgt[CH];
@@ -1402,32 +1411,48 @@ __global__ __launch_bounds__(INV_T) void knn_inverse_kernel(const int64_t* __res
     for (int c = 0; c < CH; ++c)
         if (tgt[c] >= 0) atomicAdd(&cur[tgt[c]], 1);
     __syncthreads();
-    // exclusive scans over the N (<= 1024) counts: list starts and hub slots
-    const int cnt = tid < N ? cur[tid] : 0;
-    const int is_hub = cnt > INV_HUB ? 1 : 0;
-    int incl = cnt, hincl = is_hub;
+    // exclusive scans over the N counts (target t = tid + j*1024, ascending in j): list starts and hub slots
+    int cnt[NT], start[NT], slot[NT], is_hub[NT];
+    int run = 0, hrun = 0;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(incl, o, 64), th = __shfl_up(hincl, o, 64);
-        if (lane >= o) { incl += t; hincl += th; }
+    for (int j = 0; j < NT; ++j) {
+        const int t = tid + j * INV_T;
+        cnt[j] = t < N ? cur[t] : 0;
+        is_hub[j] = cnt[j] > INV_HUB ? 1 : 0;
+        int incl = cnt[j], hincl = is_hub[j];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(incl, o, 64), uh = __shfl_up(hincl, o, 64);
+            if (lane >= o) { incl += u; hincl += uh; }
+        }
+        __syncthreads();                             // wsum free again
+        if (lane == 63) wsum[wv] = incl | (hincl << 20);               // counts < 2^20, hubs < 2^11
+        __syncthreads();
+        int base = 0, hbase = 0, tot = 0, htot = 0;
+        for (int w = 0; w < INV_T / 64; ++w) {
+            const int v = wsum[w];
+            if (w < wv) { base += v & 0xfffff; hbase += v >> 20; }
+            tot += v & 0xfffff;
+            htot += v >> 20;
+        }
+        start[j] = run + base + incl - cnt[j];
+        slot[j] = hrun + hbase + hincl - is_hub[j];
+        run += tot;
+        hrun += htot;
     }
-    if (lane == 63) wsum[wv] = incl | (hincl << 20);                   // counts < 2^20, hubs < 2^11
+    const int nh = hrun;
     __syncthreads();
-    int base = 0, hbase = 0, nh = 0;
-    for (int w = 0; w < INV_T / 64; ++w) {
-        const int v = wsum[w];
-        if (w < wv) { base += v & 0xfffff; hbase += v >> 20; }
-        nh += v >> 20;
-    }
-    const int start = base + incl - cnt;
-    const int slot = hbase + hincl - is_hub;
-    cur[tid] = start;
-    slot_of[tid] = is_hub ? (short)slot : (short)-1;
-    if (is_hub) hubs[slot] = (unsigned short)tid;
-    if (tid < N) {
-        in_ptr[(int64_t)b * (N + 1) + tid] = start;
-        if (tid == N - 1) in_ptr[(int64_t)b * (N + 1) + N] = start + cnt;
-        hub_slot[(int64_t)b * N + tid] = is_hub ? (short)slot : (short)-1;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int t = tid + j * INV_T;
+        cur[t] = start[j];
+        slot_of[t] = is_hub[j] ? (short)slot[j] : (short)-1;
+        if (is_hub[j]) hubs[slot[j]] = (unsigned short)t;
+        if (t < N) {
+            in_ptr[(int64_t)bs * (N + 1) + t] = start[j];
+            if (t == N - 1) in_ptr[(int64_t)bs * (N + 1) + N] = start[j] + cnt[j];
+            hub_slot[(int64_t)bs * N + t] = is_hub[j] ? (short)slot[j] : (short)-1;
+        }
     }
     __syncthreads();
     // short lists
@@ -1438,13 +1463,15 @@ __global__ __launch_bounds__(INV_T) void knn_inverse_kernel(const int64_t* __res
         if (tgt[c] >= 0 && hs[c] < 0) ine[atomicAdd(&cur[tgt[c]], 1)] = (unsigned short)(c * INV_T + tid);
     }
     __syncthreads();
-    if (tid < N && !is_hub)
-        for (int i = start + 1; i < start + cnt; ++i) {
-            const unsigned short v = ine[i];
-            int j = i - 1;
-            while (j >= start && ine[j] > v) { ine[j + 1] = ine[j]; --j; }
-            ine[j + 1] = v;
-        }
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+        if (tid + j * INV_T < N && !is_hub[j])
+            for (int i = start[j] + 1; i < start[j] + cnt[j]; ++i) {
+                const unsigned short v = ine[i];
+                int q = i - 1;
+                while (q >= start[j] && ine[q] > v) { ine[q + 1] = ine[q]; --q; }
+                ine[q + 1] = v;
+            }
     // hub lists (nh is uniform)
     if (nh > 0) {
 #pragma unroll
@@ -1480,9 +1507,9 @@ __global__ __launch_bounds__(INV_T) void knn_inverse_kernel(const int64_t* __res
         }
     }
     __syncthreads();
-    for (int e = tid; e < L; e += INV_T) in_edge[(int64_t)b * L + e] = ine[e];
-    for (int h = tid; h < nh; h += INV_T) hub_ids[(int64_t)b * INV_MAXHUB + h] = hubs[h];
-    if (tid == 0) hub_cnt[b] = nh;
+    for (int e = tid; e < L; e += INV_T) in_edge[(int64_t)bs * L + e] = ine[e];
+    for (int h = tid; h < nh; h += INV_T) hub_ids[(int64_t)bs * INV_MAXHUB + h] = hubs[h];
+    if (tid == 0) hub_cnt[bs] = nh;
 }
 
 // LDS image shared by the two reduction kernels: one plane of N*k floats, the transposed edge list and the hub tables.
@@ -1638,16 +1665,140 @@ __global__ __launch_bounds__(INV_T) void edge_grad_reduce_inv_kernel(const float
     }
 }
 
-// builds the transposed graph in `ws` and returns its tables; false when the geometry does not fit the LDS plan
-bool inv_graph_build(const int64_t* idx, int B, int N, int k, bool vec, void* ws, size_t ws_bytes, hipStream_t st, InvGraph* out) {
+// Slab form of edge_grad_reduce_inv_kernel for clouds whose N*k plane does not fit LDS (N = 2048, k = 40: 4 slabs of 512
+// source points = 20480 edges): for each slab the workgroup loads that slab's transposed graph, then stages the slab of
+// each of its (<= INV_PLMAX) planes in turn; gU partial sums stay in registers across the slabs, gV is complete per slab.
+constexpr int INV_PLMAX = 8;
+template <int NT>
+__global__ __launch_bounds__(INV_T) void edge_grad_reduce_slab_kernel(const float* __restrict__ GPD, const int* __restrict__ in_ptr,
+                                                                      const unsigned short* __restrict__ in_edge,
+                                                                      const int* __restrict__ hub_cnt,
+                                                                      const short* __restrict__ hub_slot, int Ctot, int N, int k,
+                                                                      int S, float* __restrict__ gUV) {
+    extern __shared__ float4 inv_lds[];
+    const int Ns = N / S, Ls = Ns * k, L4 = Ls >> 2;
+    const int64_t Ltot = (int64_t)N * k;
+    const InvLds l = inv_lds_layout(inv_lds, Ls);
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int planes = Ctot * 3;
+    const int npl = (planes - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;      // <= INV_PLMAX (host)
+    float acc[INV_PLMAX][NT];
+#pragma unroll
+    for (int i = 0; i < INV_PLMAX; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = 0.f;
+    float4 pre[INV_PF];
+    auto fetch = [&](int q) {                        // q = s * npl + i
+        const int sN = q / npl, p = blockIdx.x + (q % npl) * gridDim.x;
+        const float4* src = reinterpret_cast<const float4*>(GPD + ((int64_t)b * planes + p) * Ltot + (int64_t)sN * Ls);
+#pragma unroll
+        for (int i = 0; i < INV_PF; ++i) {
+            const int e4 = tid + i * INV_T;
+            pre[i] = e4 < L4 ? src[e4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    const int total = S * npl;
+    if (total > 0) fetch(0);
+    for (int sl = 0; sl < S; ++sl) {
+        const int bs = b * S + sl;
+        __syncthreads();                             // the previous slab's graph and plane are no longer read
+        for (int e = tid; e < Ls; e += INV_T) l.ine[e] = in_edge[(int64_t)bs * Ls + e];
+        int e0[NT], e1[NT], hs[NT];
+        const int nh = hub_cnt[bs];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int t = tid + j * INV_T;
+            e0[j] = e1[j] = 0;
+            hs[j] = -1;
+            if (t < N) {
+                e0[j] = in_ptr[(int64_t)bs * (N + 1) + t];
+                e1[j] = in_ptr[(int64_t)bs * (N + 1) + t + 1];
+                hs[j] = hub_slot[(int64_t)bs * N + t];
+                if (hs[j] >= 0) { l.hub_e0[hs[j]] = e0[j]; l.hub_e1[hs[j]] = e1[j]; }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < INV_PLMAX; ++i) {
+            if (i >= npl) break;                     // uniform
+            const int p = blockIdx.x + i * gridDim.x;
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < INV_PF; ++u) {
+                const int e4 = tid + u * INV_T;
+                if (e4 < L4) reinterpret_cast<float4*>(l.plane)[e4] = pre[u];
+            }
+            if (sl * npl + i + 1 < total) fetch(sl * npl + i + 1);
+            __syncthreads();
+            if (tid < Ns) {                          // gV of this slab's own points
+                float sv = 0.f;
+                const float4* r = reinterpret_cast<const float4*>(l.plane + tid * k);
+                for (int j = 0; j < (k >> 2); ++j) {
+                    const float4 v = r[j];
+                    sv += (v.x + v.y) + (v.z + v.w);
+                }
+                gUV[((int64_t)b * 2 * planes + planes + p) * N + sl * Ns + tid] = sv;
+            }
+            for (int h = wv; h < nh; h += INV_T / 64) {
+                float a = 0.f;
+                for (int e = l.hub_e0[h] + lane; e < l.hub_e1[h]; e += 64) a += l.plane[l.ine[e]];
+#pragma unroll
+                for (int sh = 32; sh > 0; sh >>= 1) a += __shfl_xor(a, sh, 64);
+                if (lane == 0) l.hub_g[h] = a;
+            }
+            float g[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                g[j] = 0.f;
+                if (hs[j] < 0)
+                    for (int e = e0[j]; e < e1[j]; ++e) g[j] += l.plane[l.ine[e]];
+            }
+            if (nh > 0) {                            // uniform
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    if (hs[j] >= 0) g[j] = l.hub_g[hs[j]];
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] += g[j];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < INV_PLMAX; ++i) {
+        if (i >= npl) break;
+        const int p = blockIdx.x + i * gridDim.x;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int t = tid + j * INV_T;
+            if (t < N) gUV[((int64_t)b * 2 * planes + p) * N + t] = acc[i][j];
+        }
+    }
+}
+
+// builds the transposed graph(s) in `ws` and returns the tables; false when the geometry does not fit the LDS plans.
+// *slabs = 1: one graph per cloud (N <= 1024, N*k <= INV_MAXL); > 1: N*k is a multiple of INV_MAXL and every slab of
+// N / slabs source points owns exactly INV_MAXL edges (N <= 2048), allowed only when the caller handles slabs.
+bool inv_graph_build(const int64_t* idx, int B, int N, int k, bool vec, void* ws, size_t ws_bytes, hipStream_t st, InvGraph* out,
+                     int* slabs = nullptr) {
     static const bool off = getenv("HPCS_EDGE_BWD_ATOMIC") != nullptr;
     const int64_t L = (int64_t)N * k;
-    if (off || !vec || N > INV_T || L > INV_MAXL || (L % 4) != 0) return false;
-    const InvGraph g = inv_graph_layout(ws, B, N, L);
+    if (off || !vec || (L % 4) != 0) return false;
+    int S = 1;
+    if (N > INV_T || L > INV_MAXL) {
+        if (!slabs || N > 2 * INV_T || L % INV_MAXL != 0) return false;
+        S = (int)(L / INV_MAXL);
+        if (S > INV_MAXSLAB || N % S != 0 || (int64_t)(N / S) * k != INV_MAXL) return false;
+    }
+    const int Ls = (int)(L / S);
+    const InvGraph g = inv_graph_layout(ws, B * S, N, Ls);
     if (ws_bytes < g.bytes) return false;
-    hipLaunchKernelGGL(knn_inverse_kernel, dim3(B), dim3(INV_T), 0, st, idx, N, k, g.in_ptr, g.in_edge, g.hub_cnt, g.hub_ids,
-                       g.hub_slot);
+    if (N <= INV_T)
+        hipLaunchKernelGGL((knn_inverse_kernel<1>), dim3(B * S), dim3(INV_T), 0, st, idx, N, Ls, S, g.in_ptr, g.in_edge, g.hub_cnt,
+                           g.hub_ids, g.hub_slot);
+    else
+        hipLaunchKernelGGL((knn_inverse_kernel<2>), dim3(B * S), dim3(INV_T), 0, st, idx, N, Ls, S, g.in_ptr, g.in_edge, g.hub_cnt,
+                           g.hub_ids, g.hub_slot);
     *out = g;
+    if (slabs) *slabs = S;
     return true;
 }
 int inv_groups(int B, int planes) {
@@ -1933,7 +2084,10 @@ extern "C" int hpcs_vn_edge_bwd_apply(const float* UV, const int64_t* idx, const
 extern "C" size_t hpcs_edge_grad_reduce_workspace(int B, int Ctot, int N) {
     if (B <= 0 || Ctot <= 0 || N <= 0) return 64;
     const int CP = (Ctot * 3 + 15) / 16 * 16;
-    return (size_t)B * N * CP * sizeof(float);
+    const size_t atomic_path = (size_t)B * N * CP * sizeof(float);
+    // transposed graphs: k is not known here, so room for the largest plan (INV_MAXSLAB slabs of INV_MAXL edges per cloud)
+    const size_t graphs = N <= 2 * INV_T ? inv_graph_layout(nullptr, B * INV_MAXSLAB, N, INV_MAXL).bytes : 0;
+    return atomic_path > graphs ? atomic_path : graphs;
 }
 
 // GPD [B,Ctot,3,N*k] -> gUV [B,2*Ctot,3,N]: gU = scatter-add over idx (row-contiguous atomics), gV = sum over k
@@ -1948,8 +2102,30 @@ extern "C" int hpcs_edge_grad_reduce(const float* GPD, const int64_t* idx, int B
     const bool vec = (k % 4 == 0) && (((uintptr_t)GPD & 15u) == 0);
     {   // inverse-graph path (see edge_gather_bwd_inv_kernel): no atomics, no scratch memset, GPD read once
         InvGraph ig;
-        if (inv_graph_build(idx, B, N, k, vec, ws, ws_bytes, ST, &ig)) {
+        int slabs = 1;
+        if (inv_graph_build(idx, B, N, k, vec, ws, ws_bytes, ST, &ig, &slabs)) {
             HPCS_CHECK_LAUNCH();
+            if (slabs > 1) {
+                int groups = inv_groups(B, Ctot * 3);
+                const int need = hpcs_cdiv(Ctot * 3, INV_PLMAX);
+                if (groups < need) groups = need;
+                const dim3 grid(groups, B);
+                if (N <= INV_T) {
+                    (void)hipFuncSetAttribute((const void*)edge_grad_reduce_slab_kernel<1>,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)INV_LDS_BYTES);
+                    hipLaunchKernelGGL((edge_grad_reduce_slab_kernel<1>), grid, dim3(INV_T), INV_LDS_BYTES, ST, GPD,
+                                       (const int*)ig.in_ptr, (const unsigned short*)ig.in_edge, (const int*)ig.hub_cnt,
+                                       (const short*)ig.hub_slot, Ctot, N, k, slabs, gUV);
+                } else {
+                    (void)hipFuncSetAttribute((const void*)edge_grad_reduce_slab_kernel<2>,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)INV_LDS_BYTES);
+                    hipLaunchKernelGGL((edge_grad_reduce_slab_kernel<2>), grid, dim3(INV_T), INV_LDS_BYTES, ST, GPD,
+                                       (const int*)ig.in_ptr, (const unsigned short*)ig.in_edge, (const int*)ig.hub_cnt,
+                                       (const short*)ig.hub_slot, Ctot, N, k, slabs, gUV);
+                }
+                HPCS_CHECK_LAUNCH();
+                return HPCS_OK;
+            }
             (void)hipFuncSetAttribute((const void*)edge_grad_reduce_inv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)INV_LDS_BYTES);
             hipLaunchKernelGGL(edge_grad_reduce_inv_kernel, dim3(inv_groups(B, Ctot * 3), B), dim3(INV_T), INV_LDS_BYTES, ST, GPD,

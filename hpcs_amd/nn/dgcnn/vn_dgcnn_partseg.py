@@ -83,10 +83,10 @@ class VN_DGCNN_partseg(nn.Module):
                 return e if mean else pool(e)
             e = convs[0].forward_edges(h, idx)
             convs = convs[1:]
-        elif (self.edge_mode == "materialised" and self.point_level_backward and h.size(3) <= 1024
-              and h.size(3) * self.k <= 20480 and self.k % 4 == 0):
-            # (the graph reduction keeps one N*k plane in LDS: larger clouds, e.g. N=2048 / k=40, take the edge-level
-            # backward below, which measured faster than the atomic fallback of hpcs_edge_grad_reduce)
+        elif (self.edge_mode == "materialised" and self.point_level_backward
+              and ops.graph_backward_supported(h.size(3), self.k)):
+            # (the graph reduction keeps one plane -- or one slab of a plane -- of 20480 edges in LDS; other geometries take
+            # the edge-level backward below, which measured faster than the atomic fallback of hpcs_edge_grad_reduce)
             B, N = h.size(0), h.size(3)
             idx = knn(h.reshape(B, -1, N), self.k)
             if len(convs) == 1:

@@ -716,6 +716,20 @@ class VNGraphLayerFn(torch.autograd.Function):
         return gfeat, None, gWf, gWd, ggamma, gbeta, None, None, None, None, None
 
 
+def graph_backward_supported(N, k):
+    """Geometries for which hpcs_edge_grad_reduce runs over the transposed graph (csrc/vn_layers.hip: one N*k plane, or one
+    slab of it, of 20480 floats in LDS); elsewhere it falls back to atomics and the edge-level backward is faster."""
+    L = N * k
+    if k % 4:
+        return False
+    if N <= 1024 and L <= 20480:
+        return True
+    if N <= 2048 and L % 20480 == 0:
+        S = L // 20480
+        return S <= 8 and N % S == 0 and (N // S) * k == 20480
+    return False
+
+
 def vn_graph_layer(feat, idx, Wf, Wd, gamma, beta, rmean, rvar, training, slope=0.2, pool_k=0):
     _need_cuda(feat, idx, Wf)
     return VNGraphLayerFn.apply(feat, idx, Wf, Wd, gamma, beta, rmean, rvar, training, slope, pool_k)

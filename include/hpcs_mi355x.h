@@ -125,8 +125,9 @@ int hpcs_vn_bwd_fused(const float* PD, const float* gout, const float* X, const 
  * materialised entry points above with L = N*k; pool != 0 fuses the mean over the k neighbours.
  * edge_grad_reduce: GPD [B,Ctot,3,N*k] -> gUV (gU = scatter-add over idx, gV = sum over k); also the first step of the
  * point-level backward of the MATERIALISED graph layers (reduce over the graph, then k-times smaller GEMMs).  Runs as a
- * gather over the transposed graph (built in `ws` per call; hub points are summed by whole waves) when N <= 1024,
- * N*k <= 20480 and k % 4 == 0, else with row-contiguous fp32 atomics. */
+ * gather over the transposed graph (built in `ws` per call; hub points are summed by whole waves) when k % 4 == 0 and
+ * either N <= 1024, N*k <= 20480, or N <= 2048 and the cloud splits into <= 4 slabs of N/S source points with exactly
+ * 20480 edges each (N = 2048, k = 40); else with row-contiguous fp32 atomics. */
 int hpcs_vn_edge_norm_stats(const float* UV, const int64_t* idx, int B, int Cout, int Ctot, int N, int k,
                             double* sums, int sums_zeroed, hpcs_stream_t stream);
 int hpcs_vn_edge_apply_fwd(const float* UV, const int64_t* idx, const float* mean, const float* rstd,

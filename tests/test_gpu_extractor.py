@@ -3,6 +3,8 @@ import numpy as np
 import pytest
 import torch
 
+from hpcs_amd import _lib
+
 from _det import det_cloud, det_int, det_normalish, det_params, det_uniform
 from oracle import extractor as OE, hyperbolic as OH
 
@@ -389,7 +391,35 @@ def test_edge_layer_equals_gather_then_layer(C, pool):
         relclose(a, b, 2e-5)
 
 
-@pytest.mark.parametrize("C,pool,N,k", [(1, False, 96, 8), (21, False, 96, 8), (21, True, 96, 8), (21, True, 1024, 20)])
+@pytest.mark.parametrize("B,Ctot,N,k,hub", [(2, 5, 2048, 40, True), (2, 3, 1024, 40, False), (1, 4, 2048, 20, True),
+                                            (2, 6, 1024, 20, True), (3, 2, 512, 40, False)])
+def test_edge_grad_reduce_transposed_graph(B, Ctot, N, k, hub):
+    """hpcs_edge_grad_reduce over the transposed graph -- whole planes (N*k <= 20480) and slabs of source points (N = 2048 /
+    k = 40: four slabs, two targets per thread) -- against a float64 scatter-add; hubs with thousands of incoming edges."""
+    GPD = det_normalish((B, Ctot, 3, N * k), 950 + N + k)
+    idx = det_int((B, N, k), 951 + N, N)
+    if hub:
+        idx[:, ::3, ::2] = 11
+        idx[:, 1::7, 1::4] = N - 1
+    gUV = torch.empty(B, 2 * Ctot, 3, N, device=dev)
+    nbytes = _lib.call("hpcs_edge_grad_reduce_workspace", B, Ctot, N)
+    ws = torch.empty(nbytes // 4, device=dev)
+    out = []
+    for _ in range(2):
+        gUV.fill_(float("nan"))
+        _lib.call("hpcs_edge_grad_reduce", GPD.to(dev), idx.to(dev), B, Ctot, N, k, gUV, ws, nbytes)
+        out.append(gUV.clone())
+    assert torch.equal(out[0], out[1])                               # fixed summation order
+    g64 = GPD.double().reshape(B, Ctot * 3, N * k)
+    gU = torch.zeros(B, Ctot * 3, N, dtype=torch.float64).scatter_add_(2, idx.reshape(B, 1, N * k).expand(-1, Ctot * 3, -1), g64)
+    gV = g64.reshape(B, Ctot * 3, N, k).sum(-1)
+    ref = torch.cat([gU.reshape(B, Ctot, 3, N), gV.reshape(B, Ctot, 3, N)], 1)
+    err = (out[0].cpu().double() - ref).abs().max()
+    assert float(err) <= 3e-6 * float(ref.abs().max()), float(err)
+
+
+@pytest.mark.parametrize("C,pool,N,k", [(1, False, 96, 8), (21, False, 96, 8), (21, True, 96, 8), (21, True, 1024, 20),
+                                        (21, True, 2048, 40)])
 def test_graph_layer_point_level_backward(C, pool, N, k):
     """forward_graph: forward BIT-identical to the layer on the materialised graph feature; the point-level backward
     (graph reduction first, then k-times smaller GEMMs) gives the same gradients up to fp32 reassociation."""
