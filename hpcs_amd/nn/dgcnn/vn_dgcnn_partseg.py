@@ -124,7 +124,8 @@ class VN_DGCNN_partseg(nn.Module):
         if self._drop_seed is None:
             self._drop_seed = int(torch.initial_seed()) & (2 ** 62 - 1)
         self._drop_calls += 1
-        return None, (self._drop_seed + 0x9E3779B97F4A7C15 * self._drop_calls, p)
+        # (kept below 2^63: autograd.Function arguments are inspected as C++ int64 by torch.profiler(record_shapes=True))
+        return None, ((self._drop_seed + 0x9E3779B97F4A7C15 * self._drop_calls) & (2 ** 63 - 1), p)
 
     # ---- forward -----------------------------------------------------------------------------------------
     def forward(self, x, l, drop_masks=None):
