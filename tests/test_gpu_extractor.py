@@ -1,4 +1,6 @@
 """GPU parity of the extractor path (a2-a7) against the reference's golden vectors and the CPU oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -78,7 +80,8 @@ def test_graph_feature_backward_inverse_graph(B, C, N, k, hub):
     g1 = xg.grad.clone()
     xg.grad = None
     (get_graph_feature(xg, k=k, idx=idx.to(dev)) * w.to(dev)).sum().backward()
-    assert torch.equal(g1, xg.grad)                                  # no atomics: bit-reproducible
+    if not os.environ.get("HPCS_EDGE_BWD_ATOMIC"):                   # (the forced atomic fallback is order-dependent)
+        assert torch.equal(g1, xg.grad)                              # no atomics: bit-reproducible
     wd = w.double()
     ref = torch.zeros(B, C * 3, N, dtype=torch.float64).scatter_add_(
         2, idx.reshape(B, 1, N * k).expand(-1, C * 3, -1), wd[:, :C].reshape(B, C * 3, N * k))
@@ -409,7 +412,8 @@ def test_edge_grad_reduce_transposed_graph(B, Ctot, N, k, hub):
         gUV.fill_(float("nan"))
         _lib.call("hpcs_edge_grad_reduce", GPD.to(dev), idx.to(dev), B, Ctot, N, k, gUV, ws, nbytes)
         out.append(gUV.clone())
-    assert torch.equal(out[0], out[1])                               # fixed summation order
+    if not os.environ.get("HPCS_EDGE_BWD_ATOMIC"):
+        assert torch.equal(out[0], out[1])                           # fixed summation order
     g64 = GPD.double().reshape(B, Ctot * 3, N * k)
     gU = torch.zeros(B, Ctot * 3, N, dtype=torch.float64).scatter_add_(2, idx.reshape(B, 1, N * k).expand(-1, Ctot * 3, -1), g64)
     gV = g64.reshape(B, Ctot * 3, N, k).sum(-1)
