@@ -206,9 +206,10 @@ def main():
     from hpcs_amd.dp import broadcast_parameters, init_distributed
     import torch.distributed as dist
 
-    # os.cpu_count() reports the whole host (256) while one GPU's share is 16 cores: cap torch's host threads
-    torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 16)))
     rank, local, world = init_distributed()
+    # os.cpu_count() reports the whole host (256) while one GPU's share is 16 cores: cap torch's host threads, and share
+    # the visible cores between the ranks of a node (the step's host-side torch ops are tiny)
+    torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)) // max(world, 1), 16)))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
