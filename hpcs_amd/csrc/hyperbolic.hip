@@ -215,21 +215,32 @@ __global__ void hyp_lca_bwd_kernel(const float* __restrict__ a, const float* __r
 }
 
 // ---- a15 / a8 dense matrices (API completeness; the training path never builds them) ----------------------
+__device__ __forceinline__ float hyperbolic_sim_pair(const float* __restrict__ xr, const float* __restrict__ yr, int E, float eps) {
+    const float maxn = 1.f - BALL_EPS_F32;
+    float xx = 0.f, yy = 0.f;
+    for (int e = 0; e < E; ++e) { const float a = xr[e], b = yr[e]; xx += a * a; yy += b * b; }
+    const float nx = fmaxf(sqrtf(xx), MIN_NORM), ny = fmaxf(sqrtf(yy), MIN_NORM);
+    const float sx = nx > maxn ? maxn / nx : 1.f, sy = ny > maxn ? maxn / ny : 1.f;
+    float d2 = 0.f;
+    for (int e = 0; e < E; ++e) { const float df = (xr[e] * sx - yr[e] * sy) + eps; d2 += df * df; }
+    const float ax = 1.f - xx * sx * sx, ay = 1.f - yy * sy * sy;
+    const float dxy = 1.f + 2.f * (d2 / (ax * ay));
+    return expf(-acoshf(dxy));
+}
 __global__ void hyperbolic_sim_mat_kernel(const float* __restrict__ x, const float* __restrict__ y, int M, int Mp, int E,
                                           float* __restrict__ out) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = blockIdx.y;
     if (j >= Mp) return;
-    const float maxn = 1.f - BALL_EPS_F32;
-    float xx = 0.f, yy = 0.f;
-    for (int e = 0; e < E; ++e) { const float a = x[(int64_t)i * E + e], b = y[(int64_t)j * E + e]; xx += a * a; yy += b * b; }
-    const float nx = fmaxf(sqrtf(xx), MIN_NORM), ny = fmaxf(sqrtf(yy), MIN_NORM);
-    const float sx = nx > maxn ? maxn / nx : 1.f, sy = ny > maxn ? maxn / ny : 1.f;
-    float d2 = 0.f;
-    for (int e = 0; e < E; ++e) { const float df = x[(int64_t)i * E + e] * sx - y[(int64_t)j * E + e] * sy; d2 += df * df; }
-    const float ax = 1.f - xx * sx * sx, ay = 1.f - yy * sy * sy;
-    const float dxy = 1.f + 2.f * (d2 / (ax * ay));
-    out[(int64_t)i * Mp + j] = expf(-acoshf(dxy));
+    out[(int64_t)i * Mp + j] = hyperbolic_sim_pair(x + (int64_t)i * E, y + (int64_t)j * E, E, 0.f);
+}
+// row-aligned pairs: HyperbolicDistance.pairwise_distance (hpcs/distances/poincare.py:178-187); its squared distance
+// comes from F.pairwise_distance, which adds eps = 1e-6 to every component of the difference
+__global__ void hyperbolic_sim_pairs_kernel(const float* __restrict__ x, const float* __restrict__ y, int64_t M, int E,
+                                            float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    out[i] = hyperbolic_sim_pair(x + i * E, y + i * E, E, 1e-6f);
 }
 
 // HyperbolicLCA (hpcs/distances/poincare.py:190-237), E = 2 read as complex numbers.  For a pair (x, y) of projected
@@ -430,6 +441,14 @@ extern "C" int hpcs_hyperbolic_sim_mat(const float* x, const float* y, int M, in
     if (M < 0 || Mp < 0 || E <= 0 || M > 65535) return HPCS_ERR_SHAPE;
     if (M == 0 || Mp == 0) return HPCS_OK;
     hipLaunchKernelGGL(hyperbolic_sim_mat_kernel, dim3(hpcs_cdiv(Mp, 256), M), dim3(256), 0, ST, x, y, M, Mp, E, out);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+extern "C" int hpcs_hyperbolic_sim_pairs(const float* x, const float* y, int64_t M, int E, float* out, hpcs_stream_t stream) {
+    if (!x || !y || !out) return HPCS_ERR_NULL;
+    if (M < 0 || E <= 0) return HPCS_ERR_SHAPE;
+    if (M == 0) return HPCS_OK;
+    hipLaunchKernelGGL(hyperbolic_sim_pairs_kernel, dim3(hpcs_cdiv(M, 256)), dim3(256), 0, ST, x, y, M, E, out);
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;
 }

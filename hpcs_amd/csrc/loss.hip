@@ -690,15 +690,14 @@ __global__ __launch_bounds__(SB_THREADS) void hyphc_sampled_kernel(
         const int pr_own = rp + (rp >= rank ? 1 : 0);
         const int ip_own = order[c_off + (pr_own < c_na ? pr_own : 0)];
         int in_own;
-        {   // negative: uniform over points of other classes (rejection on the label; ~1/(1 - n_a/M) draws)
-            unsigned h = hash32(hp ^ 0x9E3779B9u, (unsigned)tt + seed_hi);
-            in_own = (int)__umulhi(h, (unsigned)M);
-            int guard = 0;
-            while (labels[in_own] == c && guard < 64) {
-                h = hash32(h, 0x85EBCA6Bu + (unsigned)guard);
-                in_own = (int)__umulhi(h, (unsigned)M);
-                ++guard;
-            }
+        {   // negative: uniform over the M - n_a points of the other classes, by rank in the class-major `order`
+            // (ranks below the class's run map straight, the others skip the run): exactly the reference's
+            // n_inds = where(labels != label) draw (loss_and_miner_utils.py:43-61), one lookup, no rejection loop
+            const unsigned h = hash32(hp ^ 0x9E3779B9u, (unsigned)tt + seed_hi);
+            const int n_other = M - c_na;
+            const int rn = (int)__umulhi(h, (unsigned)(n_other > 0 ? n_other : 1));
+            const int slot = rn + (rn >= c_off ? c_na : 0);
+            in_own = order[slot < M ? slot : M - 1];
         }
         if (a_dbg && lv_own) { a_dbg[tl] = ia_own; p_dbg[tl] = ip_own; n_dbg[tl] = in_own; }
         const int cpos_own = (c == cb && pr_own < RC) ? pr_own : -1;       // slot in the LDS positive table, or -1
@@ -1486,6 +1485,72 @@ extern "C" int hpcs_cosface_bwd(const float* xn, const float* wn, const int64_t*
     if (rpb < 1) return HPCS_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(cosface_bwd_w_kernel, dim3(hpcs_cdiv(M, rpb)), dim3(TPB), (size_t)rpb * C * 4, ST, xn, labels, logits,
                        lse_rows, branch_id, n_levels, M, E, C, scale, gloss, rpb, gwn);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
+// hierarchical_loss(probabilities, targets, hierarchy_list) as a stand-alone op (hierarchical_cosface_loss.py:9-28):
+// loss_row = sum_l -log( sum_{c in branch_l(y)} prob_c ); one thread per row (API op, not on the training path: the
+// training path fuses this into hpcs_cosface_fwd/bwd).
+__global__ void hier_nll_fwd_kernel(const float* __restrict__ prob, const int64_t* __restrict__ labels,
+                                    const int32_t* __restrict__ bid, int n_levels, int M, int C, float* __restrict__ loss_rows) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= M) return;
+    const int lab = (int)labels[row];
+    const float* pr = prob + (int64_t)row * C;
+    float loss = 0.f;
+    for (int l = 0; l < n_levels; ++l) {
+        float sb = 0.f;
+        for (int c = 0; c < C; ++c)
+            if (same_branch(bid, l, C, c, lab)) sb += pr[c];
+        loss -= logf(sb);
+    }
+    loss_rows[row] = loss;
+}
+
+__global__ void hier_nll_bwd_kernel(const float* __restrict__ prob, const int64_t* __restrict__ labels,
+                                    const int32_t* __restrict__ bid, int n_levels, int M, int C, const float* __restrict__ gloss,
+                                    float* __restrict__ gprob) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= M) return;
+    const int lab = (int)labels[row];
+    const float* pr = prob + (int64_t)row * C;
+    float invS[MAX_LEVELS];
+    for (int l = 0; l < n_levels; ++l) {
+        float sb = 0.f;
+        for (int c = 0; c < C; ++c)
+            if (same_branch(bid, l, C, c, lab)) sb += pr[c];
+        invS[l] = 1.f / sb;
+    }
+    const float g = -gloss[0] / (float)M;
+    for (int c = 0; c < C; ++c) {
+        float d = 0.f;
+        for (int l = 0; l < n_levels; ++l)
+            if (same_branch(bid, l, C, c, lab)) d += invS[l];
+        gprob[(int64_t)row * C + c] = g * d;
+    }
+}
+
+extern "C" int hpcs_hier_nll_fwd(const float* prob, const int64_t* labels, const int32_t* branch_id, int n_levels, int M, int C,
+                                 float* loss_rows, hpcs_stream_t stream) {
+    if (!prob || !labels || !loss_rows) return HPCS_ERR_NULL;
+    if (M < 0 || C <= 0) return HPCS_ERR_SHAPE;
+    if (n_levels < 1 || n_levels > MAX_LEVELS || (n_levels > 1 && !branch_id)) return HPCS_ERR_SHAPE;
+    if (M == 0) return HPCS_OK;
+    hipLaunchKernelGGL(hier_nll_fwd_kernel, dim3(hpcs_cdiv(M, 64)), dim3(64), 0, ST, prob, labels, branch_id, n_levels, M, C,
+                       loss_rows);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
+extern "C" int hpcs_hier_nll_bwd(const float* prob, const int64_t* labels, const int32_t* branch_id, int n_levels, int M, int C,
+                                 const float* gloss, float* gprob, hpcs_stream_t stream) {
+    if (!prob || !labels || !gloss || !gprob) return HPCS_ERR_NULL;
+    if (M < 0 || C <= 0) return HPCS_ERR_SHAPE;
+    if (n_levels < 1 || n_levels > MAX_LEVELS || (n_levels > 1 && !branch_id)) return HPCS_ERR_SHAPE;
+    if (M == 0) return HPCS_OK;
+    hipLaunchKernelGGL(hier_nll_bwd_kernel, dim3(hpcs_cdiv(M, 64)), dim3(64), 0, ST, prob, labels, branch_id, n_levels, M, C,
+                       gloss, gprob);
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;
 }

@@ -7,6 +7,15 @@ from ..utils.poincare import (BALL_EPS, MIN_NORM, expmap_1 as expmap, hyp_dist_o
                               project)
 
 
+def _no_pml_kwargs(kwargs):
+    """The reference forwards **kwargs to PML's BaseDistance (normalize_embeddings, p, power, is_inverted); the mirror's
+    distances fix the values the reference sets itself (poincare.py:140-142, 191-193) and reject anything else."""
+    allowed = {"normalize_embeddings": False, "is_inverted": False, "p": 2, "power": 1}
+    for k, v in kwargs.items():
+        if k not in allowed or v != allowed[k]:
+            raise TypeError(f"unsupported argument {k}={v!r}")
+
+
 def _dot(u, v):
     return (u * v).sum(dim=-1, keepdim=True)
 
@@ -49,6 +58,9 @@ class HyperbolicDistance:
     normalize_embeddings = False
     p = 2
 
+    def __init__(self, **kwargs):
+        _no_pml_kwargs(kwargs)
+
     def __call__(self, query_emb, ref_emb=None):
         return self.compute_mat(query_emb, ref_emb)
 
@@ -65,11 +77,17 @@ class HyperbolicDistance:
         return out
 
     def pairwise_distance(self, query_emb, ref_emb):
-        x, y = project(query_emb), project(ref_emb)
-        xy = torch.nn.functional.pairwise_distance(x, y, p=2) ** 2
-        xx = 1 - torch.norm(x, dim=-1, p=2) ** 2
-        yy = 1 - torch.norm(y, dim=-1, p=2) ** 2
-        return torch.exp(-torch.acosh(1 + 2 * (xy / (xx * yy))))
+        """Row-aligned pairs [..., E] -> [...] (the same projected-point formula as compute_mat, one thread per pair)."""
+        if query_emb.shape != ref_emb.shape:
+            raise RuntimeError("pairwise_distance needs tensors of the same shape")
+        E = query_emb.shape[-1]
+        x = query_emb.detach().reshape(-1, E).contiguous().float()
+        y = ref_emb.detach().reshape(-1, E).contiguous().float()
+        if not x.is_cuda:
+            raise _lib.HpcsNativeError("hpcs_amd operators need HIP-device tensors (there is no CPU fallback)")
+        out = torch.empty(x.shape[0], device=x.device, dtype=torch.float32)
+        _lib.call("hpcs_hyperbolic_sim_pairs", x, y, x.shape[0], E, out)
+        return out.view(query_emb.shape[:-1])
 
 
 class HyperbolicLCA:
@@ -79,6 +97,9 @@ class HyperbolicLCA:
     is_inverted = False
     normalize_embeddings = False
     p = 2
+
+    def __init__(self, **kwargs):
+        _no_pml_kwargs(kwargs)
 
     def __call__(self, query_emb, ref_emb=None):
         return self.compute_mat(query_emb, ref_emb)

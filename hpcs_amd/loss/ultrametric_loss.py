@@ -210,6 +210,20 @@ def class_metrics(logits, labels):
     return out[0], out[1]
 
 
+def branch_ids(hierarchy_list, num_classes):
+    """[level][branch][class ids] (hpcs/data/hierarchy_list.py:9-19) -> int32 [levels, C]: the branch of every class per
+    level; a class that no branch of a level lists keeps a private id (>= C), i.e. its own probability -- what the
+    reference's in-place slice assignment leaves there (hierarchical_cosface_loss.py:13-24)."""
+    if not 1 <= len(hierarchy_list) <= 8:
+        raise ValueError("hierarchy_list must hold 1..8 levels")
+    bid = torch.arange(num_classes, dtype=torch.int32).repeat(len(hierarchy_list), 1) + num_classes
+    for lv, level in enumerate(hierarchy_list):
+        for j, branch in enumerate(level):
+            for ch in branch:
+                bid[lv, ch] = j
+    return bid.contiguous()
+
+
 class HierarchicalCosFaceLoss(CosFaceLoss):
     """hpcs/loss/hierarchical_cosface_loss.py:31-87: CosFace logits -> softmax -> per hierarchy level the class
     probabilities of a branch are replaced by the branch sum -> NLL; levels are summed.
@@ -218,14 +232,17 @@ class HierarchicalCosFaceLoss(CosFaceLoss):
     def __init__(self, num_classes, embedding_size, margin=0.35, scale=64, hierarchy_list=None):
         super().__init__(num_classes, embedding_size, margin=margin, scale=scale)
         self.hierarchy_list = hierarchy_list or []
-        if not 1 <= len(self.hierarchy_list) <= 8:
-            raise ValueError("hierarchy_list must hold 1..8 levels")
-        bid = torch.arange(num_classes, dtype=torch.int32).repeat(len(self.hierarchy_list), 1) + num_classes
-        for lv, level in enumerate(self.hierarchy_list):
-            for j, branch in enumerate(level):
-                for ch in branch:
-                    bid[lv, ch] = j
-        self.branch_id = bid.contiguous()
+        self.branch_id = branch_ids(self.hierarchy_list, num_classes)
+
+    def compute_loss(self, embeddings, labels, indices_tuple=None, ref_emb=None, ref_labels=None):
+        """PML loss-dict contract (hierarchical_cosface_loss.py:57-87): the level-summed NLL is a scalar that the
+        reference multiplies by per-element miner weights (all ones without a miner) -> 'element' losses [M]."""
+        if indices_tuple is not None or ref_emb is not None or ref_labels is not None:
+            raise NotImplementedError("miner weights / reference embeddings are never passed by HPCS (ultrametric_loss.py:165)")
+        loss = self.forward(embeddings, labels)
+        M = embeddings.shape[0]
+        return {"loss": {"losses": loss.expand(M), "indices": torch.arange(M, device=embeddings.device),
+                         "reduction_type": "element"}}
 
 
 class MetricHyperbolicLoss(torch.nn.Module):
@@ -267,11 +284,15 @@ class MetricHyperbolicLoss(torch.nn.Module):
             s = torch.tensor([float(s)], device=like.device)
         return s.reshape(1) if s.numel() == 1 else s
 
-    def get_triplets(self, n_samples, device):
-        """Miner-less fallback (ultrametric_loss.py:42-55): all pairs x t_per_anchor random thirds (host RNG)."""
+    def get_triplets(self, n_samples, device=None):
+        """Miner-less fallback (ultrametric_loss.py:42-55): all pairs x t_per_anchor random thirds; index bookkeeping on
+        the host with the reference's CPU draw order (one torch.randint of n_pairs*t_per_anchor), like the reference.
+        device=None: the reference's return (a, p, n) on the CPU; else (a, p, n, count) on `device` for HypHCFn."""
         ij = torch.combinations(torch.arange(n_samples), r=2).repeat_interleave(self.t_per_anchor, dim=0)
         k = torch.randint(n_samples, (ij.shape[0],), dtype=torch.long)
         keep = (ij[:, 0] != k) & (ij[:, 1] != k)
+        if device is None:
+            return ij[keep, 0], ij[keep, 1], k[keep]
         a, p, n = ij[keep, 0].to(device), ij[keep, 1].to(device), k[keep].to(device)
         return a, p, n, torch.full((1,), a.numel(), dtype=torch.int64, device=device)
 
@@ -287,7 +308,7 @@ class MetricHyperbolicLoss(torch.nn.Module):
                 m = self.hyp_miner
                 if plan is None:
                     plan = TripletPlan.from_labels(labels, m.t_per_anchor, m.fraction)
-                m.seed += 1
+                seed = m.next_seed()
                 if m.rng == "device" and xn.shape[1] in (16, 32, 64) and plan.T > 0:
                     # device RNG: triplets are generated inside the loss kernel (no index arrays at all)
                     lab = labels.reshape(-1).to(torch.int64).contiguous()
@@ -296,12 +317,12 @@ class MetricHyperbolicLoss(torch.nn.Module):
                     kk = upload(plan.k, xn.device, key="plan")
                     self.last_triplets = None
                     self.last_T = plan.T
-                    out = HypHCSampledFn.apply(xn, self._scale_tensor(xn), lab, order, offsets, toff, kk, plan.T, m.seed,
+                    out = HypHCSampledFn.apply(xn, self._scale_tensor(xn), lab, order, offsets, toff, kk, plan.T, seed,
                                                float(self.temperature), float(m.margin), m.type_of_triplets,
                                                self.debug_triplets)
                     self.last_kept = _LAST_KEPT[0]
                     return out
-                a, p, n = sample_with_plan(labels, plan, rng=m.rng, seed=m.seed)
+                a, p, n = sample_with_plan(labels, plan, rng=m.rng, seed=seed)
                 triplets = (a, p, n, torch.full((1,), a.numel(), dtype=torch.int64, device=xn.device))
                 kind, margin = m.type_of_triplets, float(m.margin)
             elif self.miner:

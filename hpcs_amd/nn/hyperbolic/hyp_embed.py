@@ -6,6 +6,9 @@ from ...utils.poincare import expmap0
 
 
 class ExpMap(nn.Module):
+    def __init__(self):
+        super().__init__()
+
     def forward(self, x):
         return expmap0(x)
 

@@ -73,3 +73,10 @@ def hyp_dist_o(x):
     out = torch.empty(flat.shape[0], device=x.device, dtype=torch.float32)
     _lib.call("hpcs_hyp_dist_o", flat, flat.shape[0], E, out)
     return out.view(*x.shape[:-1], 1)
+
+
+def mobius_mul(x, t):
+    """t (*) x = tanh(t artanh|x|) x/|x|   (hpcs/utils/poincare.py mobius_mul; forward-only toolbox op)."""
+    from .math import arctanh, tanh
+    n = x.norm(dim=-1, p=2, keepdim=True).clamp_min(MIN_NORM)
+    return tanh(t * arctanh(n)) * (x / n)

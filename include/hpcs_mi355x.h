@@ -208,6 +208,8 @@ int hpcs_hyp_lca_bwd(const float* a, const float* b, const float* gdist, int64_t
                      hpcs_stream_t stream);
 /* a15: HyperbolicDistance.compute_mat  hpcs/distances/poincare.py:144-176 -> sim [M,M'] */
 int hpcs_hyperbolic_sim_mat(const float* x, const float* y, int M, int Mp, int E, float* out, hpcs_stream_t stream);
+/* a15: HyperbolicDistance.pairwise_distance  hpcs/distances/poincare.py:178-187 -> sim [M] of the row-aligned pairs */
+int hpcs_hyperbolic_sim_pairs(const float* x, const float* y, int64_t M, int E, float* out, hpcs_stream_t stream);
 /* HyperbolicLCA.compute_mat / pairwise_distance  hpcs/distances/poincare.py:190-237 (E == 2 only: the reference reads the
  * points as complex numbers): min(d(o,x), d(o,y), d(o, midpoint of the geodesic x-y)) on projected points.
  * pairs == 0: out [M, Mp]; pairs != 0 (M == Mp): row-aligned pairs, out [M]. */
@@ -286,6 +288,13 @@ int hpcs_cosface_fwd(const float* xn, const float* wn, const int64_t* labels, co
 int hpcs_cosface_bwd(const float* xn, const float* wn, const int64_t* labels, const float* logits,
                      const float* lse_rows, const int32_t* branch_id, int n_levels, int M, int E, int C, float scale,
                      const float* gloss, float* gxn, float* gwn, hpcs_stream_t stream);
+/* hierarchical_loss(probabilities, targets, hierarchy_list)  hpcs/loss/hierarchical_cosface_loss.py:9-28  as a
+ * stand-alone op on already-softmaxed probabilities prob [M,C]: loss_rows[i] = sum_l -log(sum_{c in branch_l(y_i)} prob[i,c])
+ * (the caller means over M: F.nll_loss's reduction).  bwd: gprob [M,C] overwritten with gloss/M * d loss_row/d prob. */
+int hpcs_hier_nll_fwd(const float* prob, const int64_t* labels, const int32_t* branch_id, int n_levels, int M, int C,
+                      float* loss_rows, hpcs_stream_t stream);
+int hpcs_hier_nll_bwd(const float* prob, const int64_t* labels, const int32_t* branch_id, int n_levels, int M, int C,
+                      const float* gloss, float* gprob, hpcs_stream_t stream);
 /* ---- next row f3: in-step metrics  hpcs/models/base_hyp_hc.py:88-99,126-130 -----------------------------------------
  * The reference feeds softmax(get_logits(...)) to torchmetrics (pinned 0.10.1 in hpcs-env.yaml, but the constructor calls
  * need >= 0.11: Accuracy(task='multiclass', top_k=1) = micro accuracy; MulticlassJaccardIndex = macro IoU over the

@@ -14,7 +14,8 @@ Reference lines restated (relative to /root/reference):
   TripletMarginLoss.compute_loss         hpcs/miner/triplet_margin_loss.py:34-65
   MetricHyperbolicLoss                   hpcs/loss/ultrametric_loss.py:16-143
   CosFace body (verbatim mirror in-tree) hpcs/loss/hierarchical_cosface_loss.py:57-87
-  hierarchical_loss                      hpcs/loss/hierarchical_cosface_loss.py:9-28
+  hierarchical_loss                      hpcs/loss/hierarchical_cosface_loss.py:9-28   (pinned: reference_vectors_r2.npz)
+  get_triplets (miner-less fallback)     hpcs/loss/ultrametric_loss.py:42-55           (pinned: reference_vectors_r2.npz)
   RAdam.step                             hpcs/optim/radam.py:59-134
 """
 import torch
@@ -200,6 +201,18 @@ def hyphc_loss_gathered(x_poincare, triplets, scale, temperature):
     w_ord = torch.sum(sim * soft, dim=-1, keepdim=True)
     total = torch.sum(sim, dim=-1, keepdim=True) - w_ord
     return torch.mean(total) + mat.mean()
+
+
+def all_pairs_triplets(n_samples, t_per_anchor, generator=None):
+    """MetricHyperbolicLoss.get_triplets (ultrametric_loss.py:42-55), the miner-less fallback: every pair (i<j)
+    repeated t_per_anchor times, one uniform third index each (ONE torch.randint of the full length on the CPU
+    generator), triplets whose third index hits i or j dropped."""
+    n_triplets = t_per_anchor * (n_samples * (n_samples - 1) // 2)
+    ij = torch.combinations(torch.arange(n_samples), r=2).repeat_interleave(t_per_anchor, dim=0)
+    kw = {} if generator is None else {"generator": generator}
+    k = torch.randint(n_samples, (n_triplets,), dtype=torch.long, **kw)
+    keep = (ij[:, 0] != k) & (ij[:, 1] != k)
+    return ij[keep, 0], ij[keep, 1], k[keep]
 
 
 def metric_hyperbolic_loss(x_poincare, labels, scale, W=None, *, margin=1.0, t_per_anchor=50, fraction=1.2,

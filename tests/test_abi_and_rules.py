@@ -85,3 +85,71 @@ def test_oracle_is_test_infrastructure_only():
     for f in list(_py_files(os.path.join(ROOT, "hpcs_amd"))) + [os.path.join(ROOT, "__graft_entry__.py")]:
         assert "/root/reference" not in open(f).read(), f
     assert "TEST INFRASTRUCTURE" in open(os.path.join(ROOT, "oracle", "__init__.py")).read()
+
+
+def _compatible(ref_params, got):
+    """Every call that binds under the reference's signature binds under ours with the same meaning: the reference's
+    named parameters appear in the same order with the same defaults; whatever we add has a default (or is **kwargs).
+    A reference `**kwargs` (PML base-class arguments) needs `**kwargs` or extra defaulted keywords on our side; a
+    reference `*args` (forwarded to a PML constructor) may be spelled out as named parameters."""
+    import inspect
+    ref_named = [(n, d) for n, kind, d in ref_params if not kind.startswith("VAR_")]
+    ref_var_kw = any(kind == "VAR_KEYWORD" for _, kind, _ in ref_params)
+    ref_var_pos = any(kind == "VAR_POSITIONAL" for _, kind, _ in ref_params)
+    gp = list(got.parameters.values())
+    g_named = [p_ for p_ in gp if p_.kind in (p_.POSITIONAL_OR_KEYWORD, p_.KEYWORD_ONLY, p_.POSITIONAL_ONLY)]
+    g_var_kw = any(p_.kind == p_.VAR_KEYWORD for p_ in gp)
+    names = [p_.name for p_ in g_named]
+    pos = -1
+    for n, d in ref_named:
+        if n not in names:
+            return f"parameter {n!r} missing"
+        i = names.index(n)
+        if i < pos:
+            return f"parameter {n!r} out of order"
+        pos = i
+        gd = g_named[i].default
+        if d is not None and (gd is inspect.Parameter.empty or repr(gd) != d):
+            return f"default of {n!r}: reference {d}, ours {gd!r}"
+        # (a default ADDED where the reference has none keeps every reference call valid)
+    ref_names = {n for n, _ in ref_named}
+    for p_ in g_named:
+        if p_.name not in ref_names and p_.default is inspect.Parameter.empty and not ref_var_pos:
+            return f"extra required parameter {p_.name!r}"
+    if ref_var_kw and not g_var_kw and not any(p_.name not in ref_names for p_ in g_named):
+        return "reference takes **kwargs, ours takes no further keywords"
+    return None
+
+
+def test_operator_api_signatures_match_reference():
+    """tests/golden/api_signatures.json = the parameter lists (name, kind, default) of the reference's importable
+    hot-path symbols (generated by tests/golden/make_golden_r2.py, stored as data); every one must exist in hpcs_amd
+    (hpcs.X -> hpcs_amd.X) and accept every call the reference's signature accepts (SURVEY 8b drop-in boundary)."""
+    import importlib
+    import inspect
+    import json
+    sig = json.load(open(os.path.join(ROOT, "tests", "golden", "api_signatures.json")))
+    assert len(sig) >= 60
+    problems = []
+    for key, ref_params in sorted(sig.items()):
+        parts = key.split(".")
+        mod, rest = None, None
+        for i in range(len(parts), 0, -1):
+            try:
+                mod = importlib.import_module(".".join(parts[:i]).replace("hpcs", "hpcs_amd", 1))
+                rest = parts[i:]
+                break
+            except ImportError:
+                continue
+        obj = mod
+        try:
+            for r in rest:
+                obj = obj.__dict__[r] if (inspect.isclass(obj) and r in obj.__dict__) else getattr(obj, r)
+            got = inspect.signature(obj)
+        except (AttributeError, KeyError, TypeError, ValueError) as e:
+            problems.append(f"{key}: missing ({e!r})")
+            continue
+        why = _compatible(ref_params, got)
+        if why:
+            problems.append(f"{key}: {why}\n      reference {ref_params}\n      ours      {got}")
+    assert not problems, "\n".join(problems)
