@@ -25,8 +25,12 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TF = 157.3     # MI355X_MICROARCH.md: fp32 matrix peak (v_mfma_f32_32x32x2_f32)
 
 
-def synthetic_batch(B, N, num_class, num_categories, seed):
-    """N(0,I) clouds normalised to the unit ball, Voronoi part labels, uniform categories."""
+def synthetic_batch(B, N, num_class, num_categories, seed, labels="voronoi"):
+    """N(0,I) clouds normalised to the unit ball, uniform categories, part labels either
+    "voronoi"   : Voronoi cells of num_class seeded centroids (spatially coherent parts; the benchmark's labels), or
+    "invariant" : rotation-INVARIANT parts -- radial shells x local-density halves (equal-mass bins over the batch).  A
+                  rotation-invariant extractor fed SO(3)-augmented clouds cannot learn absolute-position (Voronoi) parts
+                  (accuracy stays at chance); these it can, so training curves / trajectory tests use them."""
     pts = torch.empty(B, N, 3)
     for b in range(B):
         g = torch.Generator().manual_seed(1234 + seed * 100003 + b)
@@ -34,9 +38,24 @@ def synthetic_batch(B, N, num_class, num_categories, seed):
         p = p - p.mean(0, keepdim=True)
         pts[b] = p / p.norm(dim=1).max()
     g = torch.Generator().manual_seed(99 + seed)
-    cent = torch.randn(num_class, 3, generator=g)
-    cent = cent / cent.norm(dim=1, keepdim=True) * torch.rand(num_class, 1, generator=g) ** (1 / 3) * 0.8
-    tgt = torch.cdist(pts.reshape(-1, 3), cent).argmin(dim=1)
+    if labels == "invariant":
+        n_shell = max(num_class // 2, 1)
+        r = pts.norm(dim=2).reshape(-1)                                         # [B*N]
+        d = torch.cdist(pts, pts)                                               # [B,N,N]
+        dens = d.topk(9, dim=2, largest=False).values[:, :, -1].reshape(-1)     # distance to the 8th neighbour
+        shell = (r.argsort().argsort().float() / r.numel() * n_shell).long().clamp_(max=n_shell - 1)
+        tgt = torch.zeros_like(shell)
+        for s_ in range(n_shell):                                               # density halves inside every shell
+            m = shell == s_
+            med = dens[m].median()
+            tgt[m] = 2 * s_ + (dens[m] > med).long()
+        tgt = tgt.clamp_(max=num_class - 1)
+    elif labels == "voronoi":
+        cent = torch.randn(num_class, 3, generator=g)
+        cent = cent / cent.norm(dim=1, keepdim=True) * torch.rand(num_class, 1, generator=g) ** (1 / 3) * 0.8
+        tgt = torch.cdist(pts.reshape(-1, 3), cent).argmin(dim=1)
+    else:
+        raise ValueError("labels must be 'voronoi' or 'invariant'")
     present = torch.bincount(tgt, minlength=num_class)
     missing = (present == 0).nonzero().flatten().tolist()
     for i, c in enumerate(missing):                      # every class non-empty (round-robin fallback)

@@ -197,6 +197,7 @@ def vn_dgcnn_partseg(x, l, P, k, training=False, pooling="mean", drop_masks=None
     aux.update(x1=x1, x2=x2, x3=x3)
 
     g = vn_linear_leaky_relu(x123, P, "conv6", training)         # [B,341,3,N]
+    aux.update(g6=g)
     g = torch.cat((g, g.mean(dim=-1, keepdim=True).expand(g.size())), 1)
     g, z0 = vn_std_feature(g, P, "std_feature", training)
     loc = torch.einsum("bijm,bjkm->bikm", x123, z0).reshape(B, -1, N)   # [B,189,N]
@@ -206,6 +207,7 @@ def vn_dgcnn_partseg(x, l, P, k, training=False, pooling="mean", drop_masks=None
     cat = _conv_bn_act(l.reshape(B, -1, 1), P, "conv7", training)        # [B,64,1]
     h = torch.cat((torch.cat((glob, cat), dim=1).repeat(1, 1, N), loc), dim=1)   # [B,2299,N]
     h = _conv_bn_act(h, P, "conv8", training)
+    aux.update(h8=h)
     if drop_masks is not None:
         h = h * drop_masks[0]
     h = _conv_bn_act(h, P, "conv9", training)
