@@ -23,6 +23,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TF = 157.3     # MI355X_MICROARCH.md: fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+VALU_F32_PEAK_TF = 78.6      # MI355X_MICROARCH.md: fp32 vector peak, scalar v_fma_f32 (157 packed)
+L2_GATHER_PEAK_GBS = 17800.0  # MI355X_MICROARCH.md "Indexed rows": L2-resident row gather, 16.8-18.8 TB/s chip-wide
 
 
 def synthetic_batch(B, N, num_class, num_categories, seed, labels="voronoi"):
@@ -64,6 +66,36 @@ def synthetic_batch(B, N, num_class, num_categories, seed, labels="voronoi"):
     return pts, cat, tgt.view(B, N)
 
 
+def hierarchy_for(num_class):
+    """Level lists [level][branch][class ids] for the hierarchical (PartNet) loss.  C = 39 / 51: the lists the reference's
+    hierarchy parser produced for PartNet-format trees with Chair's / Table's level sizes (tests/golden/
+    hierarchy_lists.json, made by tests/golden/make_golden_r2.py; the PartNet label files themselves are dataset files,
+    absent here).  Other C: three nested levels of consecutive runs (groups of 8, groups of 3, leaves)."""
+    path = os.path.join(ROOT, "tests", "golden", "hierarchy_lists.json")
+    if os.path.exists(path):
+        for v in json.load(open(path)).values():
+            if v["num_class"] == num_class:
+                return v["hierarchy_list"]
+    C = num_class
+    return [[list(range(i, min(i + 8, C))) for i in range(0, C, 8)],
+            [list(range(i, min(i + 3, C))) for i in range(0, C, 3)], [[c] for c in range(C)]]
+
+
+# BASELINE.json configs (per-GPU shapes); "2" is the configuration the metric is quoted on
+PRESETS = {
+    "1": dict(batch=4, points=256, k=10, num_class=4, num_categories=16, hierarchical=False,
+              name="BASELINE configs[0] geometry: ShapeNet single category, fixed_points=256, k=10, batch=4"),
+    "2": dict(batch=32, points=1024, k=20, num_class=50, num_categories=16, hierarchical=False,
+              name="BASELINE configs[1]: ShapeNet-like fixed_points=1024, k=20, batch=32 per GPU"),
+    "3": dict(batch=32, points=1024, k=20, num_class=39, num_categories=1, hierarchical=True,
+              name="BASELINE configs[2]: PartNet Chair level-3 (39 parts, one category, hierarchical loss), "
+                   "fixed_points=1024, k=20, batch=32 per GPU"),
+    "5": dict(batch=16, points=2048, k=40, num_class=51, num_categories=1, hierarchical=True,
+              name="BASELINE configs[4] per-GPU shape: PartNet Table level-3 (51 parts, hierarchical loss), "
+                   "fixed_points=2048, k=40, batch=16 per GPU"),
+}
+
+
 def build_step(args, device):
     from hpcs_amd.nn.dgcnn import VN_DGCNN_partseg
     from hpcs_amd.nn.hyperbolic import ExpMap
@@ -72,10 +104,8 @@ def build_step(args, device):
     feat = VN_DGCNN_partseg(in_channels=3, out_features=args.embedding, k=args.k, dropout=0.5, pooling="mean",
                             num_categories=args.num_categories)
     hier = None
-    if args.hierarchical:          # synthetic 3-level part hierarchy: groups of 8, groups of 3, leaves
-        C = args.num_class
-        hier = [[list(range(i, min(i + 8, C))) for i in range(0, C, 8)],
-                [list(range(i, min(i + 3, C))) for i in range(0, C, 3)], [[c] for c in range(C)]]
+    if args.hierarchical:
+        hier = hierarchy_for(args.num_class)
     step = HypHCStep(feat, ExpMap(), hyp_size=args.embedding, num_class=args.num_class,
                      num_categories=args.num_categories, lr=0.05, margin=0.35, t_per_anchor=50, fraction=1.2,
                      temperature=0.05, trade_off=0.1, miner=True, cosface=True, train_rotation="so3", rng="device",
@@ -97,6 +127,7 @@ def pmc_traffic(kernel_substr):
 
 
 EXTRA_STEPS = 3
+HOST_BURST = 3               # steps enqueued back to back from an idle queue to time the host side of a step
 EVENT_EVERY = 4              # dominant-kernel event pairs in every 4th timed step
 EXTRA_NOTE = f"HIP events in {EXTRA_STEPS} further steps after the timed region"
 
@@ -202,6 +233,7 @@ def knn_steady_state(dev, N, k, B=4096, D=3, reps=5):
     byts, flops = B * N * (4 * D + 8 * k), 2.0 * D * N * N * B
     return {"B": B, "D": D, "N": N, "k": k, "ms_per_launch": round(t * 1e3, 3), "achieved_GBs": round(byts / t / 1e9, 1),
             "frac_hbm": round(byts / t / 1e9 / HBM_PEAK_GBS, 4), "fp32_tflops": round(flops / t / 1e12, 2),
+            "frac_valu": round(flops / t / 1e12 / VALU_F32_PEAK_TF, 4),
             "clouds_per_s": round(B / t)}
 
 
@@ -210,16 +242,31 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=32, help="clouds per GPU")
-    ap.add_argument("--points", type=int, default=1024)
-    ap.add_argument("--k", type=int, default=20)
+    ap.add_argument("--config", choices=sorted(PRESETS), default=None,
+                    help="BASELINE.json configuration preset (default: 2, the one the metric is quoted on)")
+    ap.add_argument("--batch", type=int, default=None, help="clouds per GPU")
+    ap.add_argument("--points", type=int, default=None)
+    ap.add_argument("--k", type=int, default=None)
     ap.add_argument("--embedding", type=int, default=32)
-    ap.add_argument("--num-class", type=int, default=50)
-    ap.add_argument("--num-categories", type=int, default=16)
-    ap.add_argument("--hierarchical", action="store_true", help="PartNet-style hierarchical CosFace (cfg-3/5)")
+    ap.add_argument("--num-class", type=int, default=None)
+    ap.add_argument("--num-categories", type=int, default=None)
+    ap.add_argument("--hierarchical", action="store_true", default=None,
+                    help="PartNet-style hierarchical CosFace (configs 3 / 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
+    preset = PRESETS[args.config or "2"]
+    custom = []
+    for key in ("batch", "points", "k", "num_class", "num_categories", "hierarchical"):
+        if getattr(args, key) is None:
+            setattr(args, key, preset[key])
+        elif getattr(args, key) != preset[key]:
+            custom.append(f"{key}={getattr(args, key)}")
+    workload = preset["name"] if not custom else \
+        "custom shape (" + ", ".join(custom) + f") on top of config {args.config or '2'}: fixed_points={args.points}, " \
+        f"k={args.k}, batch={args.batch} per GPU, parts={args.num_class}" + (", hierarchical loss" if args.hierarchical else "")
+    workload += f"; eucl/hyp_embedding={args.embedding}, vn_dgcnn_partseg + ExpMap + miner + HypHC + " \
+                f"{'hierarchical ' if args.hierarchical else ''}CosFace + RAdam"
 
     from hpcs_amd import _lib
     from hpcs_amd.dp import broadcast_parameters, init_distributed
@@ -227,8 +274,9 @@ def main():
 
     rank, local, world = init_distributed()
     # os.cpu_count() reports the whole host (256) while one GPU's share is 16 cores: cap torch's host threads, and share
-    # the visible cores between the ranks of a node (the step's host-side torch ops are tiny)
-    torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)) // max(world, 1), 16)))
+    # the visible cores between the ranks of THIS node (the step's host-side torch ops are tiny)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)) // max(local_world, 1), 16)))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
@@ -249,44 +297,62 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def one_step():
+        return step.training_step(pts_d, cat_d, tgt_d, targets_host=tgt)
+
     for _ in range(args.warmup):
-        step.training_step(pts_d, cat_d, tgt_d, targets_host=tgt)
+        one_step()
+    n_tune = 0
+    while step.graph_mode() is None and n_tune < 16:      # auto mode: capture + timing of replay against eager (untimed)
+        one_step()
+        n_tune += 1
+    mode = step.graph_mode() or "eager"
     barrier()
     timed = not args.no_kernel_timing
+    # HIP events (on the launch stream) around every launch of the two heaviest kernels, live in the timed region:
+    # hpcs_gemm_tn calls that dispatch gemm_tn_kernel<128,128,16,2,2> (M > 64 and >= 32 tiles, see gemm.hip) and
+    # hpcs_hyphc_sampled.  An event pair is a barrier packet on each side (on every launch of every step they cost 3 % of
+    # the step), so the pairs are recorded in every EVENT_EVERY-th timed step -- still inside the timed region, still
+    # every launch of those kernels in those steps.  When the steady state replays a hipGraph those sampled steps run
+    # eagerly (events cannot be wrapped around the nodes of a replayed graph).
+    sampled = [False]
     if timed:
-        # HIP events (on the launch stream) around every launch of the DOMINANT kernel only, live in the timed region:
-        # hpcs_gemm_tn calls that dispatch gemm_tn_kernel<128,128,16,2,2> (M > 64 and >= 32 tiles, see gemm.hip)
-        # (an event pair is a barrier packet on each side: on every launch of every step they cost 3 % of the step, so the
-        # pairs are recorded in every EVENT_EVERY-th timed step -- still inside the timed region, still every launch of
-        # the kernel in those steps)
-        _lib.PROFILE = {"hpcs_gemm_tn": []}
-        sampled = [False]
-        _lib.PROFILE_FILTER = lambda name, tg: sampled[0] and is_big_mfma_gemm(tg)
+        _lib.PROFILE = {"hpcs_gemm_tn": [], "hpcs_hyphc_sampled": []}
+        _lib.PROFILE_FILTER = lambda name, tg: sampled[0] and (name != "hpcs_gemm_tn" or is_big_mfma_gemm(tg))
+    kept_hist = []
     t0 = time.perf_counter()
     for i_step in range(args.steps):
-        if timed:
-            sampled[0] = (i_step % EVENT_EVERY) == 0
-        losses = step.training_step(pts_d, cat_d, tgt_d, targets_host=tgt)
-    dt_host = time.perf_counter() - t0          # launches enqueued; the GPU may still be running
+        sampled[0] = timed and (i_step % EVENT_EVERY) == 0
+        if sampled[0] and mode == "graph":
+            losses = step._eager_step(pts_d, cat_d, tgt_d, tgt)
+        else:
+            losses = one_step()
+        if i_step in (0, args.steps - 1):
+            kept_hist.append(step.metric_hyp_loss.last_kept.clone())       # device scalar: no sync
     barrier()
     dt = time.perf_counter() - t0
+    sampled[0] = False
+    # host cost of enqueueing one step, measured on a short burst from an idle queue (over the whole timed loop the host
+    # is throttled by the ring of per-step parameter slots once it runs several steps ahead of the GPU)
+    t1 = time.perf_counter()
+    for _ in range(HOST_BURST):
+        one_step()
+    host_ms = (time.perf_counter() - t1) / HOST_BURST * 1e3
+    torch.cuda.synchronize()
     prof, _lib.PROFILE = _lib.PROFILE, None
     _lib.PROFILE_FILTER = None
     prof_extra = {}
     if timed:                  # every rank runs them: the step contains the gradient all-reduce
-        # the secondary kernels (EdgeConv GEMM, loss, kNN) are timed in EXTRA_STEPS further steps OUTSIDE the timed
+        # the secondary kernels (EdgeConv GEMM, kNN) are timed in EXTRA_STEPS further EAGER steps OUTSIDE the timed
         # region, so that their event pairs do not perturb the reported throughput
-        _lib.PROFILE = {"hpcs_knn": [], "hpcs_gemm_tn": [], "hpcs_hyphc_bwd": [], "hpcs_hyphc_sampled": []}
+        _lib.PROFILE = {"hpcs_knn": [], "hpcs_gemm_tn": []}
         for _ in range(EXTRA_STEPS):
-            step.training_step(pts_d, cat_d, tgt_d, targets_host=tgt)
+            step._eager_step(pts_d, cat_d, tgt_d, tgt)
         torch.cuda.synchronize()
         prof_extra, _lib.PROFILE = _lib.PROFILE, None
     if world > 1:
         dist.barrier()
-    try:
-        step._last_kept = int(step.metric_hyp_loss.last_kept.item())
-    except Exception:
-        step._last_kept = 0
+    kept_window = [int(k_.item()) for k_ in kept_hist]
 
     t = torch.tensor([dt], device=device)
     if world > 1:
@@ -297,9 +363,11 @@ def main():
     if rank != 0:
         return
     clouds = args.batch * world * args.steps
+    cps = clouds / dt
+    T_s = int(step.metric_hyp_loss.last_T)
     out = {
-        "metric": "point-clouds/sec training step (N=1024,k=20)",
-        "value": round(clouds / dt, 2),
+        "metric": "point-clouds/sec training step (N=%d,k=%d)" % (args.points, args.k),
+        "value": round(cps, 2),
         "unit": "point-clouds/s",
         "n_gpus": world,
         "steps": args.steps,
@@ -310,46 +378,81 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: ShapeNet-like fixed_points=%d, k=%d, eucl/hyp_embedding=%d, "
-                               "batch=%d per GPU, vn_dgcnn_partseg + ExpMap + miner + HypHC + CosFace + RAdam"
-                               % (args.points, args.k, args.embedding, args.batch),
+        "config": {"workload": workload,
                    "global_batch": args.batch * world, "num_class": args.num_class,
                    "parallelism": f"dp{world} (per-replica BN and mining, one flat-gradient all-reduce)",
+                   "step_mode": f"{mode} (HPCS_GRAPH={os.environ.get('HPCS_GRAPH', 'auto')}"
+                                + (f"; measured ms/step replay vs eager: {step._tune['measured_ms']}"
+                                   if getattr(step, '_tune', None) and step._tune.get('measured_ms') else "") + ")",
+                   "untimed_steps_before_the_timed_region": args.warmup + n_tune,
                    "triplet_rng": "device counter RNG (statistically equivalent to the reference's CPU torch.randint)",
                    "metrics_in_step": "accuracy + IoU of the CosFace logits computed on device every step (base_hyp_hc.py:126-130), "
                                       "no host sync; last step: acc=%.4f iou=%.4f" % (float(losses["acc"]), float(losses["iou"])),
                    "final_total_loss": round(loss_val, 6),
-                   "host_enqueue_ms_per_step": round(dt_host / args.steps * 1e3, 3),
-                   "triplets_sampled_per_step_rank0": int(step.metric_hyp_loss.last_T)},
+                   "host_enqueue_ms_per_step": round(host_ms, 3),
+                   "triplets_sampled_per_step_rank0": T_s,
+                   "triplets_kept_first_and_last_timed_step": kept_window},
     }
+    # step-level roofline (SURVEY 8d / BASELINE.md 4): clouds/s x algorithmic fwd+bwd FLOPs per cloud / fp32 MFMA peak
+    flop_cloud = {(1024, 20): 18.2e9, (256, 10): 4.15e9, (2048, 40): 41.98e9}.get((args.points, args.k))
+    if flop_cloud:
+        out["roofline_step"] = {"bound": "mfma", "unit": "TFLOP/s", "peak": MFMA_F32_PEAK_TF * world,
+                                "achieved": round(cps * flop_cloud / 1e12, 2),
+                                "frac": round(cps * flop_cloud / 1e12 / (MFMA_F32_PEAK_TF * world), 4),
+                                "flop_per_cloud_fwd_bwd": flop_cloud,
+                                "note": "SURVEY 8(d)'s un-hoisted count (the reference's op sequence); the build skips "
+                                        "work by hoisting conv8's 2110 and vn1's 341 N-constant channels"}
     if timed and prof:
         def dur(lst):
             return [(e0.elapsed_time(e1) * 1e-3, tag) for e0, e1, tag in lst]
-        kn = dur(prof_extra["hpcs_knn"])
+        n_sampled = len(range(0, args.steps, EVENT_EVERY))
+        step_s = dt / args.steps
         gm = dur(prof["hpcs_gemm_tn"])
+        hb = dur(prof["hpcs_hyphc_sampled"])
+        kn = dur(prof_extra["hpcs_knn"])
         gm_extra = dur(prof_extra["hpcs_gemm_tn"])
-        dt_extra = dt / args.steps * EXTRA_STEPS          # step time scale for the shares of the extra-phase kernels
-        B, N, k = args.batch, args.points, args.k
-        # kNN: algorithmic bytes per launch = B*N*(4*D + 8*k)   (SURVEY 8d); tag = (B, D, N, k)
-        kn_bytes = sum(t_[0] * t_[2] * (4 * t_[1] + 8 * t_[3]) for _, t_ in kn)
-        kn_flops = sum(2.0 * t_[1] * t_[2] * t_[2] * t_[0] for _, t_ in kn)
-        kn_time = sum(d for d, _ in kn)
-        # dominant kernel = gemm_tn_kernel<128,128,16,2,2>: every hpcs_gemm_tn launch with M > 64 (the M <= 64
-        # EdgeConv launches run the HBM-bound <64,128,16,1,4> instantiation and are reported separately)
         big = [(d, t_) for d, t_ in gm if is_big_mfma_gemm(t_)]
         small = [(d, t_) for d, t_ in gm_extra if t_[7] <= 64 and not is_small_gemm(t_)]
         gm_flops = sum(gemm_flops(t_) for _, t_ in big)
         gm_time = sum(d for d, _ in big)
+        hb_time = sum(d for d, _ in hb)
+        rank_gemm = 1 if gm_time >= hb_time else 2
         out["roofline"] = {"kernel": "gemm_tn_kernel<128,128,16,2,2> (hpcs_gemm_tn, M > 64: VN dense layers + heads, "
-                                     "forward and data-grad)",
+                                     "forward and data-grad; the class with the largest share of the step among MFMA-/HBM-"
+                                     "bound kernels)",
                            "bound": "mfma", "achieved": round(gm_flops / gm_time / 1e12, 3), "peak": MFMA_F32_PEAK_TF,
                            "unit": "TFLOP/s", "frac": round(gm_flops / gm_time / 1e12 / MFMA_F32_PEAK_TF, 4),
                            "traffic": pmc_traffic("gemm_tn_kernel<128"),
                            "algorithmic_bytes_per_launch": round(sum(gemm_bytes(t_) for _, t_ in big) / len(big)),
                            "launches": len(big), "avg_launch_us": round(1e6 * gm_time / len(big), 2),
-                           "share_of_step": round(gm_time / (dt / args.steps * len(range(0, args.steps, EVENT_EVERY))), 4),
+                           "share_of_step": round(gm_time / (step_s * n_sampled), 4),
+                           "rank_by_time": rank_gemm,
                            "measured": f"HIP events around every launch of the kernel in every {EVENT_EVERY}th step of "
-                                       "the timed region"}
+                                       "the timed region" + (" (those steps run eagerly; the others replay the hipGraph)"
+                                                             if mode == "graph" else "")}
+        if hb:
+            E_ = args.embedding
+            kept = kept_window[-1] if kept_window else T_s // 2
+            # rows gathered through L2 per launch: per sampled triplet positive + negative rows (the anchor's row is
+            # reused along its run of ~k_c triplets), per kept triplet the two gradient rows added back (positive: LDS
+            # table, negative: global atomics).  The 4 MB embedding table is L2-resident: HBM sees ~2 GB (PMC), not this.
+            l2_bytes = T_s * (2 * 4 * E_) + kept * (2 * 4 * E_)
+            out["roofline_hyphc"] = {"kernel": "hyphc_sampled_kernel<4,true> (hpcs_hyphc_sampled: triplets generated "
+                                               "in-kernel, miner rule inline, loss + gradient in one sweep)",
+                                     "bound": "l2-gather / valu issue / atomic units (not hbm, not mfma)",
+                                     "achieved": round(l2_bytes * len(hb) / hb_time / 1e9, 1), "unit": "GB/s of gathered rows",
+                                     "peak": L2_GATHER_PEAK_GBS,
+                                     "frac": round(l2_bytes * len(hb) / hb_time / 1e9 / L2_GATHER_PEAK_GBS, 4),
+                                     "traffic": pmc_traffic("hyphc_sampled_kernel"),
+                                     "gathered_bytes_per_launch": l2_bytes, "launches": len(hb),
+                                     "avg_launch_us": round(1e6 * hb_time / len(hb), 2),
+                                     "share_of_step": round(hb_time / (step_s * n_sampled), 4),
+                                     "rank_by_time": 3 - rank_gemm,
+                                     "triplets_sampled": T_s, "triplets_kept": kept,
+                                     "measured": "HIP events around the entry point (three 8-byte memsets + the kernel) in "
+                                                 f"every {EVENT_EVERY}th step of the timed region",
+                                     "note": "peak = L2-resident row-gather rate (MI355X_MICROARCH 'Indexed rows', "
+                                             "16.8-18.8 TB/s); float atomics ~1.3 TB/s of added bytes chip-wide"}
         if small:
             sb = sum(gemm_bytes(t_) for _, t_ in small)
             st_ = sum(d for d, _ in small)
@@ -359,36 +462,25 @@ def main():
                                          "traffic": pmc_traffic("gemm_tn_kernel<64"),
                                          "algorithmic_bytes_per_launch": round(sb / len(small)), "launches": len(small),
                                          "avg_launch_us": round(1e6 * st_ / len(small), 2),
-                                         "share_of_step": round(st_ / dt_extra, 4), "measured": EXTRA_NOTE}
-        hb = dur(prof_extra.get("hpcs_hyphc_sampled", []) or prof_extra.get("hpcs_hyphc_bwd", []))
-        if hb:
-            T_s = int(step.metric_hyp_loss.last_T)
-            E_ = args.embedding
-            # per sampled triplet: 3 int64 indices + 3 gathered rows; per kept triplet: 2 rows of atomic adds (+1/16 anchor row)
-            kept = int(getattr(step, "_last_kept", 0)) or T_s // 2
-            hb_bytes = len(hb) * (T_s * (24 + 3 * 4 * E_) + kept * (2 * 4 * E_ + 4 * E_ // 16))
-            hb_time = sum(d for d, _ in hb)
-            out["roofline_hyphc_bwd"] = {"kernel": "HypHC one-pass kernel (loss + gradient; atomic-add bound)",
-                                         "bound": "hbm", "achieved": round(hb_bytes / hb_time / 1e9, 1), "peak": HBM_PEAK_GBS,
-                                         "unit": "GB/s", "frac": round(hb_bytes / hb_time / 1e9 / HBM_PEAK_GBS, 4),
-                                         "traffic": pmc_traffic("hyphc_sampled_kernel") or pmc_traffic("hyphc_kernel<4, true"),
-                                         "algorithmic_bytes_per_launch": round(hb_bytes / len(hb)), "launches": len(hb),
-                                         "avg_launch_us": round(1e6 * hb_time / len(hb), 2),
-                                         "share_of_step": round(hb_time / dt_extra, 4), "measured": EXTRA_NOTE,
-                                         "triplets_sampled": T_s,
-                                         "triplets_kept": kept,
-                                         "note": "float atomics run at ~1.3 TB/s of added bytes chip-wide (MI355X_MICROARCH)"}
-        out["roofline_knn"] = {"kernel": "knn_sumsq_kernel + knn_mfma_sort_kernel (hpcs_knn, D=3 and D=63 launches)",
-                               "bound": "hbm",
-                               "achieved": round(kn_bytes / kn_time / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(kn_bytes / kn_time / 1e9 / HBM_PEAK_GBS, 5),
-                               "traffic": pmc_traffic("knn_mfma_sort_kernel") or pmc_traffic("knn_mfma_kernel"),
-                               "algorithmic_bytes_per_launch": round(kn_bytes / len(kn)),
-                               "launches": len(kn), "avg_launch_us": round(1e6 * kn_time / len(kn), 2),
-                               "fp32_tflops": round(kn_flops / kn_time / 1e12, 3), "measured": EXTRA_NOTE,
-                               "note": "arithmetic intensity 36-313 flop/B: bound by the VALU top-k selection, not by HBM"}
-        if world == 1:
-            out["roofline_knn"]["steady_state"] = knn_steady_state(device, args.points, args.k)
+                                         "share_of_step": round(st_ / (step_s * EXTRA_STEPS), 4), "measured": EXTRA_NOTE}
+        if kn:
+            # kNN: algorithmic bytes per launch = B*N*(4*D + 8*k)   (SURVEY 8d); tag = (B, D, N, k)
+            kn_bytes = sum(t_[0] * t_[2] * (4 * t_[1] + 8 * t_[3]) for _, t_ in kn)
+            kn_flops = sum(2.0 * t_[1] * t_[2] * t_[2] * t_[0] for _, t_ in kn)
+            kn_time = sum(d for d, _ in kn)
+            out["roofline_knn"] = {"kernel": "knn_sumsq_kernel + knn_mfma_*_kernel (hpcs_knn, D=3 and D=63 launches)",
+                                   "bound": "valu (top-k selection; arithmetic intensity 36-313 flop/B is far above the "
+                                            "HBM ridge, SURVEY 8d)",
+                                   "achieved": round(kn_flops / kn_time / 1e12, 3), "unit": "TFLOP/s (2*D*N^2 per cloud)",
+                                   "peak": VALU_F32_PEAK_TF, "frac": round(kn_flops / kn_time / 1e12 / VALU_F32_PEAK_TF, 4),
+                                   "hbm_GBs": round(kn_bytes / kn_time / 1e9, 2),
+                                   "hbm_frac": round(kn_bytes / kn_time / 1e9 / HBM_PEAK_GBS, 5),
+                                   "traffic": pmc_traffic("knn_mfma"),
+                                   "algorithmic_bytes_per_launch": round(kn_bytes / len(kn)),
+                                   "launches": len(kn), "avg_launch_us": round(1e6 * kn_time / len(kn), 2),
+                                   "measured": EXTRA_NOTE}
+            if world == 1:
+                out["roofline_knn"]["steady_state"] = knn_steady_state(device, args.points, args.k)
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args)
     print(json.dumps(out))

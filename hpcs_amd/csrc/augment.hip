@@ -15,6 +15,7 @@ __device__ __forceinline__ unsigned hash_u32(unsigned a, unsigned b) {
 __device__ __forceinline__ float unit_open(unsigned h) { return ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f); }   // (0,1)
 
 __global__ __launch_bounds__(256) void so3_rotate_kernel(const float* __restrict__ points, int N, uint64_t seed,
+                                                         const uint64_t* __restrict__ seed_dev,
                                                          const float* __restrict__ rot_in, float* __restrict__ x_out,
                                                          float* __restrict__ rot_out) {
     __shared__ float R[9];
@@ -25,6 +26,7 @@ __global__ __launch_bounds__(256) void so3_rotate_kernel(const float* __restrict
             for (int i = 0; i < 9; ++i) R[i] = rot_in[b * 9 + i];
         } else {
             // four standard normals by Box-Muller from four counter-hash uniforms
+            if (seed_dev) seed = *seed_dev;          // graph-replayable launches read the seed from device memory
             const unsigned s0 = (unsigned)seed, s1 = (unsigned)(seed >> 32);
             const float u0 = unit_open(hash_u32(s0 ^ 0xA511E9B3u, 4u * b + s1)), u1 = unit_open(hash_u32(s0 ^ 0x63D83595u, 4u * b + 1u + s1));
             const float u2 = unit_open(hash_u32(s0 ^ 0x9E3779B9u, 4u * b + 2u + s1)), u3 = unit_open(hash_u32(s0 ^ 0x7F4A7C15u, 4u * b + 3u + s1));
@@ -55,13 +57,13 @@ __global__ __launch_bounds__(256) void so3_rotate_kernel(const float* __restrict
 }
 }  // namespace
 
-extern "C" int hpcs_so3_rotate_points(const float* points, int B, int N, uint64_t seed, const float* rot_in, float* x_out,
-                                      float* rot_out, hpcs_stream_t stream) {
+extern "C" int hpcs_so3_rotate_points(const float* points, int B, int N, uint64_t seed, const uint64_t* seed_dev,
+                                      const float* rot_in, float* x_out, float* rot_out, hpcs_stream_t stream) {
     if (!points || !x_out) return HPCS_ERR_NULL;
     if (B < 0 || N <= 0 || B > 65535) return HPCS_ERR_SHAPE;
     if (B == 0) return HPCS_OK;
-    hipLaunchKernelGGL(so3_rotate_kernel, dim3(hpcs_cdiv(N, 256), B), dim3(256), 0, (hipStream_t)stream, points, N, seed, rot_in,
-                       x_out, rot_out);
+    hipLaunchKernelGGL(so3_rotate_kernel, dim3(hpcs_cdiv(N, 256), B), dim3(256), 0, (hipStream_t)stream, points, N, seed, seed_dev,
+                       rot_in, x_out, rot_out);
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;
 }

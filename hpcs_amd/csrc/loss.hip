@@ -615,7 +615,8 @@ template <int EPL, bool GRAD>
 __global__ __launch_bounds__(SB_THREADS) void hyphc_sampled_kernel(
     const float* __restrict__ xn, const int64_t* __restrict__ labels, const int32_t* __restrict__ order,
     const int32_t* __restrict__ offsets, const int64_t* __restrict__ cls_toff, const int32_t* __restrict__ cls_k, int C,
-    int M, int64_t T, uint64_t seed, const float* __restrict__ scale, float temperature, float margin, int kind, int RC,
+    int M, int64_t T_arg, uint64_t seed, const uint64_t* __restrict__ seed_dev, const float* __restrict__ scale,
+    float temperature, float margin, int kind, int RC,
     double* __restrict__ loss_sum, unsigned long long* __restrict__ kept_out, float* __restrict__ gxn,
     double* __restrict__ gscale, int64_t* __restrict__ a_dbg, int64_t* __restrict__ p_dbg, int64_t* __restrict__ n_dbg,
     unsigned perm_mul, int seg_len) {
@@ -631,6 +632,11 @@ __global__ __launch_bounds__(SB_THREADS) void hyphc_sampled_kernel(
     __shared__ double red[16];
     __shared__ int cb_sh[3];
 
+    // The number of sampled triplets is the plan's last prefix entry; T_arg only sized the grid (>= T: a replayed graph
+    // keeps the grid of the largest batch seen so far, surplus workgroups fall through the bounds tests below).
+    const int64_t T = cls_toff[C];
+    (void)T_arg;
+    if (seed_dev) seed = *seed_dev;
     const float sraw = *scale;
     const float sc = fminf(fmaxf(sraw, 1e-4f), 1.f);
     const bool s_live = sraw >= 1e-4f && sraw <= 1.f;
@@ -641,6 +647,7 @@ __global__ __launch_bounds__(SB_THREADS) void hyphc_sampled_kernel(
     const int sub0 = lane & ~(SUB - 1);
     const unsigned pblock = (unsigned)(((uint64_t)blockIdx.x * perm_mul) % gridDim.x);
     const int64_t block_base = (int64_t)pblock * ((int64_t)SB_GROUPS * seg_len);
+    if (block_base >= T) return;             // surplus workgroup of a grid sized for a larger batch (uniform per block)
 
     if (threadIdx.x == 0) {
         const int cb = class_of(cls_toff, C, block_base < T ? block_base : T - 1);
@@ -1598,7 +1605,8 @@ extern "C" int hpcs_triplet_margin_bwd(const float* xn, int E, const int64_t* a,
 
 extern "C" int hpcs_hyphc_sampled(const float* xn, const int64_t* labels, const int32_t* order, const int32_t* offsets,
                                   const int64_t* cls_toff, const int32_t* cls_k, int C, int M, int E, int64_t T,
-                                  uint64_t seed, const float* scale, float temperature, float margin, int kind,
+                                  uint64_t seed, const uint64_t* seed_dev, const float* scale, float temperature,
+                                  float margin, int kind,
                                   double* loss_sum, int64_t* kept, float* gxn, double* gscale, int64_t* a_dbg,
                                   int64_t* p_dbg, int64_t* n_dbg, hpcs_stream_t stream) {
     if (!xn || !labels || !order || !offsets || !cls_toff || !cls_k || !scale || !loss_sum || !kept) return HPCS_ERR_NULL;
@@ -1653,11 +1661,11 @@ extern "C" int hpcs_hyphc_sampled(const float* xn, const int64_t* labels, const 
             (void)hipFuncSetAttribute((const void*)hyphc_sampled_kernel<EPL, true>,                                   \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                          \
             hipLaunchKernelGGL((hyphc_sampled_kernel<EPL, true>), grid, dim3(SB_THREADS), lds, ST, xn, labels, order, \
-                               offsets, cls_toff, cls_k, C, M, T, seed, scale, temperature, margin, kind, RC, loss_sum, \
+                               offsets, cls_toff, cls_k, C, M, T, seed, seed_dev, scale, temperature, margin, kind, RC, loss_sum, \
                                (unsigned long long*)kept, gxn, gscale, a_dbg, p_dbg, n_dbg, perm_mul, seg_len);                \
         } else {                                                                                                      \
             hipLaunchKernelGGL((hyphc_sampled_kernel<EPL, false>), grid, dim3(SB_THREADS), lds, ST, xn, labels, order, \
-                               offsets, cls_toff, cls_k, C, M, T, seed, scale, temperature, margin, kind, RC, loss_sum, \
+                               offsets, cls_toff, cls_k, C, M, T, seed, seed_dev, scale, temperature, margin, kind, RC, loss_sum, \
                                (unsigned long long*)kept, gxn, gscale, a_dbg, p_dbg, n_dbg, perm_mul, seg_len);                \
         }                                                                                                             \
     }

@@ -935,8 +935,9 @@ __global__ void bn_stats_kernel(const float* __restrict__ Y, int B, int C, int64
 __global__ void bn_act_fwd_kernel(const float* __restrict__ Y, const float* __restrict__ mean,
                                   const float* __restrict__ rstd, const float* __restrict__ gamma,
                                   const float* __restrict__ beta, const float* __restrict__ mask, int B, int C, int64_t L,
-                                  float slope, float* __restrict__ out, unsigned long long dseed, unsigned dthr,
-                                  float dinv) {
+                                  float slope, float* __restrict__ out, unsigned long long dseed,
+                                  const unsigned long long* __restrict__ dseed_dev, unsigned dthr, float dinv) {
+    if (dseed_dev) dseed = *dseed_dev;
     const int c = blockIdx.y;
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (int64_t)B * L) return;
@@ -952,8 +953,10 @@ __global__ void bn_act_bwd_reduce_kernel(const float* __restrict__ Y, const floa
                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                          const float* __restrict__ mask, int B, int C, int64_t L, float slope,
-                                         double* __restrict__ red_out, unsigned long long dseed, unsigned dthr, float dinv) {
+                                         double* __restrict__ red_out, unsigned long long dseed,
+                                         const unsigned long long* __restrict__ dseed_dev, unsigned dthr, float dinv) {
     __shared__ double red[16];
+    if (dseed_dev) dseed = *dseed_dev;
     const int c = blockIdx.y;
     const int64_t total = (int64_t)B * L;
     const int64_t e0 = (int64_t)blockIdx.x * (TPB * ITEMS) + threadIdx.x;
@@ -987,7 +990,9 @@ __global__ void bn_act_bwd_apply_kernel(const float* __restrict__ Y, const float
                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                         const float* __restrict__ mask, const double* __restrict__ red, int training,
                                         int B, int C, int64_t L, float slope, float* __restrict__ gY,
-                                        unsigned long long dseed, unsigned dthr, float dinv) {
+                                        unsigned long long dseed, const unsigned long long* __restrict__ dseed_dev,
+                                        unsigned dthr, float dinv) {
+    if (dseed_dev) dseed = *dseed_dev;
     const int c = blockIdx.y;
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (int64_t)B * L) return;
@@ -2167,42 +2172,44 @@ static inline unsigned drop_thresh(float p) { return p > 0.f && p < 1.f ? (unsig
 static inline float drop_inv(float p) { return p > 0.f && p < 1.f ? 1.0f / (1.0f - p) : 1.0f; }
 
 extern "C" int hpcs_bn_act_fwd(const float* Y, const float* mean, const float* rstd, const float* gamma,
-                               const float* beta, const float* mask, uint64_t drop_seed, float drop_p, int B, int C, int64_t L,
-                               float slope, float* out, hpcs_stream_t stream) {
+                               const float* beta, const float* mask, uint64_t drop_seed, const uint64_t* drop_seed_dev,
+                               float drop_p, int B, int C, int64_t L, float slope, float* out, hpcs_stream_t stream) {
     if (!Y || !mean || !rstd || !gamma || !beta || !out) return HPCS_ERR_NULL;
     if (bad_dims(B, C, L) || C > 65535) return HPCS_ERR_SHAPE;
     if (B == 0) return HPCS_OK;
     hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(hpcs_cdiv((int64_t)B * L, TPB), C), dim3(TPB), 0, ST, Y, mean, rstd, gamma,
-                       beta, mask, B, C, L, slope, out, (unsigned long long)drop_seed, drop_thresh(drop_p), drop_inv(drop_p));
+                       beta, mask, B, C, L, slope, out, (unsigned long long)drop_seed,
+                       (const unsigned long long*)drop_seed_dev, drop_thresh(drop_p), drop_inv(drop_p));
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;
 }
 
 extern "C" int hpcs_bn_act_bwd_reduce(const float* Y, const float* gout, const float* mean, const float* rstd,
                                       const float* gamma, const float* beta, const float* mask, uint64_t drop_seed,
-                                      float drop_p, int B, int C, int64_t L, float slope, double* red, int red_zeroed,
+                                      const uint64_t* drop_seed_dev, float drop_p, int B, int C, int64_t L, float slope,
+                                      double* red, int red_zeroed,
                                       hpcs_stream_t stream) {
     if (!Y || !gout || !mean || !rstd || !gamma || !beta || !red) return HPCS_ERR_NULL;
     if (bad_dims(B, C, L) || C > 65535) return HPCS_ERR_SHAPE;
     if (!red_zeroed && hipMemsetAsync(red, 0, sizeof(double) * 2 * C, ST) != hipSuccess) return HPCS_ERR_HIP;
     if (B == 0) return HPCS_OK;
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(hpcs_cdiv((int64_t)B * L, TPB * ITEMS), C), dim3(TPB), 0, ST, Y, gout,
-                       mean, rstd, gamma, beta, mask, B, C, L, slope, red, (unsigned long long)drop_seed, drop_thresh(drop_p),
-                       drop_inv(drop_p));
+                       mean, rstd, gamma, beta, mask, B, C, L, slope, red, (unsigned long long)drop_seed,
+                       (const unsigned long long*)drop_seed_dev, drop_thresh(drop_p), drop_inv(drop_p));
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;
 }
 
 extern "C" int hpcs_bn_act_bwd_apply(const float* Y, const float* gout, const float* mean, const float* rstd,
                                      const float* gamma, const float* beta, const float* mask, uint64_t drop_seed,
-                                     float drop_p, const double* red, int training, int B, int C, int64_t L, float slope,
+                                     const uint64_t* drop_seed_dev, float drop_p, const double* red, int training, int B, int C, int64_t L, float slope,
                                      float* gY, hpcs_stream_t stream) {
     if (!Y || !gout || !mean || !rstd || !gamma || !beta || !gY || (training && !red)) return HPCS_ERR_NULL;
     if (bad_dims(B, C, L) || C > 65535) return HPCS_ERR_SHAPE;
     if (B == 0) return HPCS_OK;
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(hpcs_cdiv((int64_t)B * L, TPB), C), dim3(TPB), 0, ST, Y, gout, mean,
                        rstd, gamma, beta, mask, red, training, B, C, L, slope, gY, (unsigned long long)drop_seed,
-                       drop_thresh(drop_p), drop_inv(drop_p));
+                       (const unsigned long long*)drop_seed_dev, drop_thresh(drop_p), drop_inv(drop_p));
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;
 }

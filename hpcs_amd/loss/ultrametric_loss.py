@@ -105,7 +105,9 @@ class HypHCSampledFn(torch.autograd.Function):
     sampler / filter passes; loss, kept count and unscaled gradient in one sweep (hpcs_hyphc_sampled)."""
 
     @staticmethod
-    def forward(ctx, xn, scale, labels, order, offsets, toff, kk, T, seed, temperature, margin, kind, debug):
+    def forward(ctx, xn, scale, labels, order, offsets, toff, kk, T, seed, temperature, margin, kind, debug, seed_dev=None):
+        """T sizes the grid (>= toff[C], the count the kernel reads on the device); seed_dev (int64[1] device tensor)
+        overrides the by-value seed -- both so that a captured launch can be replayed with per-step values."""
         M, E = xn.shape
         dev = xn.device
         C = kk.numel()
@@ -118,8 +120,8 @@ class HypHCSampledFn(torch.autograd.Function):
         if debug is not None:
             dbg = [torch.zeros(T, dtype=torch.int64, device=dev) for _ in range(3)]
             debug.extend(dbg)
-        call("hpcs_hyphc_sampled", xn, labels, order, offsets, toff, kk, C, M, E, T, int(seed) & (2 ** 63 - 1), scale,
-             temperature, margin, _KIND[kind], loss_sum, kept, gxn_raw, gscale_raw, dbg[0], dbg[1], dbg[2])
+        call("hpcs_hyphc_sampled", xn, labels, order, offsets, toff, kk, C, M, E, T, int(seed) & (2 ** 63 - 1), seed_dev,
+             scale, temperature, margin, _KIND[kind], loss_sum, kept, gxn_raw, gscale_raw, dbg[0], dbg[1], dbg[2])
         _LAST_KEPT[0] = kept
         colsum = torch.empty(E, dtype=torch.float64, device=dev)
         call("hpcs_colsum", xn, M, E, colsum)
@@ -137,7 +139,7 @@ class HypHCSampledFn(torch.autograd.Function):
         inv = (g32.double() / kept.double().clamp_min(1)).float()
         gxn = torch.addcmul((colsum / float(M * M)).float().mul(g32).unsqueeze(0), gxn_raw, inv)
         gscale = (gscale_raw * inv.double()).float().view_as(scale)
-        return (gxn, gscale) + (None,) * 11
+        return (gxn, gscale) + (None,) * 12
 
 
 class CosFaceFn(torch.autograd.Function):
@@ -296,7 +298,9 @@ class MetricHyperbolicLoss(torch.nn.Module):
         a, p, n = ij[keep, 0].to(device), ij[keep, 1].to(device), k[keep].to(device)
         return a, p, n, torch.full((1,), a.numel(), dtype=torch.int64, device=device)
 
-    def compute_hyp(self, x_poincare, labels, plan=None, triplets=None, xn=None):
+    def compute_hyp(self, x_poincare, labels, plan=None, triplets=None, xn=None, step_ctx=None):
+        """step_ctx (hpcs_amd.step.StepCtx, optional): the step driver has already drawn the miner's seed and uploaded the
+        plan into the per-step parameter block; the kernels read both from there."""
         if xn is None:
             xn = L2RowsFn.apply(x_poincare)
         kind, margin = None, 0.0
@@ -308,18 +312,23 @@ class MetricHyperbolicLoss(torch.nn.Module):
                 m = self.hyp_miner
                 if plan is None:
                     plan = TripletPlan.from_labels(labels, m.t_per_anchor, m.fraction)
-                seed = m.next_seed()
+                from_ctx = step_ctx is not None and step_ctx.plan is plan and step_ctx.miner_seed is not None
+                seed = step_ctx.miner_seed if from_ctx else m.next_seed()
                 if m.rng == "device" and xn.shape[1] in (16, 32, 64) and plan.T > 0:
                     # device RNG: triplets are generated inside the loss kernel (no index arrays at all)
                     lab = labels.reshape(-1).to(torch.int64).contiguous()
                     order, offsets = class_index(lab, plan.C)
-                    toff = upload(plan.toff, xn.device, key="plan")
-                    kk = upload(plan.k, xn.device, key="plan")
+                    if from_ctx:
+                        toff, kk, seed_dev, T_grid = step_ctx.toff_dev, step_ctx.kk_dev, step_ctx.seed_dev["miner"], step_ctx.T_grid
+                    else:
+                        toff = upload(plan.toff, xn.device, key="plan")
+                        kk = upload(plan.k, xn.device, key="plan")
+                        seed_dev, T_grid = None, plan.T
                     self.last_triplets = None
                     self.last_T = plan.T
-                    out = HypHCSampledFn.apply(xn, self._scale_tensor(xn), lab, order, offsets, toff, kk, plan.T, seed,
+                    out = HypHCSampledFn.apply(xn, self._scale_tensor(xn), lab, order, offsets, toff, kk, T_grid, seed,
                                                float(self.temperature), float(m.margin), m.type_of_triplets,
-                                               self.debug_triplets)
+                                               self.debug_triplets, seed_dev)
                     self.last_kept = _LAST_KEPT[0]
                     return out
                 a, p, n = sample_with_plan(labels, plan, rng=m.rng, seed=seed)
@@ -343,12 +352,12 @@ class MetricHyperbolicLoss(torch.nn.Module):
         with torch.no_grad():
             return self.loss_cosface.logits_and_loss(embeddings, labels)[1]
 
-    def compute_loss(self, x_euclidean, x_poincare, labels, *args, plan=None, plan_metric=None):
+    def compute_loss(self, x_euclidean, x_poincare, labels, *args, plan=None, plan_metric=None, step_ctx=None):
         if not x_poincare.is_cuda:
             raise _lib.HpcsNativeError("hpcs_amd losses need HIP-device tensors (there is no CPU fallback)")
         labels = labels.reshape(-1)
         xn = L2RowsFn.apply(x_poincare)
-        loss_hyperbolic = self.compute_hyp(x_poincare, labels, plan=plan, xn=xn)
+        loss_hyperbolic = self.compute_hyp(x_poincare, labels, plan=plan, xn=xn, step_ctx=step_ctx)
         if self.cosface:
             loss_metric = self.loss_cosface(x_poincare, labels.long(), xn=xn)
         else:
@@ -356,10 +365,11 @@ class MetricHyperbolicLoss(torch.nn.Module):
             loss_metric = self.loss_triplet(x_poincare, labels, (a, p, n), count=count)
         return {"loss_hyp": {"losses": loss_hyperbolic}, "loss_metric": {"losses": loss_metric}}
 
-    def make_plan(self, labels_cpu_or_counts):
-        """Per-class sampling plan from host-side labels (call before the forward pass: no mid-step sync)."""
+    def make_plan(self, labels_cpu_or_counts, minlength=0):
+        """Per-class sampling plan from host-side labels (call before the forward pass: no mid-step sync).
+        minlength: pad the class table (absent classes sample nothing), so that its size does not depend on the batch."""
         t = labels_cpu_or_counts
-        counts = torch.bincount(t.reshape(-1).to(torch.int64).cpu())
+        counts = torch.bincount(t.reshape(-1).to(torch.int64).cpu(), minlength=minlength)
         return TripletPlan(counts, self.t_per_anchor, self.fraction)
 
     def anneal_temperature(self):

@@ -112,30 +112,42 @@ class VN_DGCNN_partseg(nn.Module):
             bump(bn)
         return out
 
-    def _dropout(self, p, given):
+    def next_drop_seed(self):
+        """Seed of the next dropout call's in-kernel counter RNG: (torch.initial_seed() and the data-parallel rank at first
+        use, running call counter), mixed -- reproducible under torch.manual_seed, different on every rank,
+        statistically equivalent to torch's Philox stream, not bit-identical to it."""
+        from ...miner.triplet_margin_miner import mix64
+        if self._drop_seed is None:
+            import torch.distributed as dist
+            rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+            self._drop_seed = mix64((int(torch.initial_seed()) & (2 ** 64 - 1)) ^ mix64(0xA0761D6478BD642F * (rank + 1) & (2 ** 64 - 1)))
+        self._drop_calls += 1
+        # (kept below 2^63: autograd.Function arguments are inspected as C++ int64 by torch.profiler(record_shapes=True))
+        return mix64(self._drop_seed ^ mix64(self._drop_calls)) & (2 ** 63 - 1)
+
+    def _dropout(self, p, given, seed=None):
         """(mask, drop) for ops.bn_act: an explicit multiplier tensor when the caller supplies one (parity tests), else
-        (seed, p) for the in-kernel counter RNG -- the mask of nn.Dropout (vn_dgcnn_partseg.py:46,50) is never stored.
-        The seed stream is (torch.initial_seed() at first use, running call counter): reproducible under
-        torch.manual_seed, statistically equivalent to torch's Philox stream, not bit-identical to it."""
+        (seed, p[, device word holding the seed]) for the in-kernel counter RNG -- the mask of nn.Dropout
+        (vn_dgcnn_partseg.py:46,50) is never stored.  `seed` = (value, device tensor) prepared by the step driver."""
         if given is not None:
             return given, None
         if not self.training or p <= 0.0:
             return None, None
-        if self._drop_seed is None:
-            self._drop_seed = int(torch.initial_seed()) & (2 ** 62 - 1)
-        self._drop_calls += 1
-        # (kept below 2^63: autograd.Function arguments are inspected as C++ int64 by torch.profiler(record_shapes=True))
-        return None, ((self._drop_seed + 0x9E3779B97F4A7C15 * self._drop_calls) & (2 ** 63 - 1), p)
+        if seed is not None:
+            return None, (seed[0], p, seed[1])
+        return None, (self.next_drop_seed(), p)
 
     # ---- forward -----------------------------------------------------------------------------------------
-    def forward(self, x, l, drop_masks=None):
-        """drop_masks=(m1,m2): optional already-scaled dropout multipliers [B,256,N] (parity tests)."""
+    def forward(self, x, l, drop_masks=None, drop_seeds=None):
+        """drop_masks=(m1,m2): optional already-scaled dropout multipliers [B,256,N] (parity tests).
+        drop_seeds=((seed1, dev1), (seed2, dev2)): the two dropout seeds drawn ahead by the step driver
+        (next_drop_seed) together with the device words that hold them (hpcs_amd/_params.py)."""
         if not x.is_cuda:
             raise RuntimeError("hpcs_amd.VN_DGCNN_partseg runs on a HIP device only (no CPU fallback)")
         with batch_counters():            # one multi-tensor add for all BatchNorm step counters
-            return self._forward(x, l, drop_masks)
+            return self._forward(x, l, drop_masks, drop_seeds)
 
-    def _forward(self, x, l, drop_masks):
+    def _forward(self, x, l, drop_masks, drop_seeds=None):
         B, N = x.size(0), x.size(2)
         h = x.unsqueeze(1)
 
@@ -162,11 +174,13 @@ class VN_DGCNN_partseg(nn.Module):
         bias8 = ops.row_linear(vec, W8[:, :gc], sink=(W8p, (slice(None), slice(0, gc), 0)))  # [B,256]
         y8 = ops.chan_mix(loc, W8[:, gc:], bias8, sink=(W8p, (slice(None), slice(gc, None), 0)))
         bn = self.bn8
-        m1, d1 = self._dropout(self.dropout, None if drop_masks is None else drop_masks[0])
+        m1, d1 = self._dropout(self.dropout, None if drop_masks is None else drop_masks[0],
+                               None if drop_seeds is None else drop_seeds[0])
         hh = ops.bn_act(y8, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training, 0.2, m1, d1)
         if self.training:
             bump(bn)
-        m2, d2 = self._dropout(self.dropout, None if drop_masks is None else drop_masks[1])
+        m2, d2 = self._dropout(self.dropout, None if drop_masks is None else drop_masks[1],
+                               None if drop_seeds is None else drop_seeds[1])
         hh = self._head(self.conv9, hh, mask=m2, drop=d2)
         hh = self._head(self.conv10, hh)
         hh = self._head(self.conv11, hh)

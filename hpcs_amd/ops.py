@@ -746,10 +746,12 @@ class BnActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y, gamma, beta, rmean, rvar, training, slope, mask, drop=None):
-        """mask: explicit [B,C,L] multiplier; drop = (seed, p): the multiplier is generated inside the kernels."""
+        """mask: explicit [B,C,L] multiplier; drop = (seed, p[, seed_dev]): the multiplier is generated inside the
+        kernels; seed_dev (int64[1] device tensor) overrides the by-value seed (graph-replayable launches)."""
         ctx.bnparams = (gamma, beta)
         dseed, dp = (int(drop[0]) & (2 ** 63 - 1), float(drop[1])) if (drop is not None and mask is None) else (0, 0.0)
-        ctx.drop = (dseed, dp)
+        dsd = drop[2] if (drop is not None and mask is None and len(drop) > 2) else None
+        ctx.drop = (dseed, dp, dsd)
         y = _f32c(y)
         B, C = y.shape[0], y.shape[1]
         L = y[0, 0].numel()
@@ -762,7 +764,7 @@ class BnActFn(torch.autograd.Function):
             call("hpcs_bn_stats", y, B, C, L, sums, 1)
         call("hpcs_bn_finalize", sums, C, B * L, BN_EPS, BN_MOMENTUM, rmean, rvar, mean, rstd, 1 if training else 0)
         out = torch.empty_like(y)
-        call("hpcs_bn_act_fwd", y, mean, rstd, gamma, beta, mask, dseed, dp, B, C, L, slope, out)
+        call("hpcs_bn_act_fwd", y, mean, rstd, gamma, beta, mask, dseed, dsd, dp, B, C, L, slope, out)
         ctx.save_for_backward(y, mean, rstd, gamma, beta, mask)
         ctx.cfg = (B, C, L, slope, bool(training))
         return out
@@ -773,11 +775,11 @@ class BnActFn(torch.autograd.Function):
         B, C, L, slope, training = ctx.cfg
         g = _f32c(g)
         red = _zeros64(2 * C, g.device)
-        dseed, dp = ctx.drop
-        call("hpcs_bn_act_bwd_reduce", y, g, mean, rstd, gamma, beta, mask, dseed, dp, B, C, L, slope, red, 1)
+        dseed, dp, dsd = ctx.drop
+        call("hpcs_bn_act_bwd_reduce", y, g, mean, rstd, gamma, beta, mask, dseed, dsd, dp, B, C, L, slope, red, 1)
         gy = torch.empty_like(y)
-        call("hpcs_bn_act_bwd_apply", y, g, mean, rstd, gamma, beta, mask, dseed, dp, red, 1 if training else 0, B, C, L, slope,
-             gy)
+        call("hpcs_bn_act_bwd_apply", y, g, mean, rstd, gamma, beta, mask, dseed, dsd, dp, red, 1 if training else 0, B, C, L,
+             slope, gy)
         ggamma, gbeta = _bn_grads(ctx.bnparams, red, C, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
         return gy, ggamma, gbeta, None, None, None, None, None, None
 

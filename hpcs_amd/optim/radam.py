@@ -45,33 +45,58 @@ class RAdam(torch.optim.Adam):
             out.append((lanes, torch.frombuffer(blob, dtype=torch.uint8), len(ents), rows_total))
         return out
 
+    def _live_params(self, group):
+        params = []
+        for p in group["params"]:
+            if p.grad is None:
+                continue
+            if p.grad.is_sparse:
+                raise RuntimeError("Riemannian Adam does not support sparse gradients")
+            if not p.is_cuda:
+                raise _lib.HpcsNativeError("hpcs_amd.optim.RAdam needs HIP-device parameters (no CPU fallback)")
+            if not (p.is_contiguous() and p.grad.is_contiguous()):
+                raise _lib.HpcsNativeError("RAdam needs contiguous parameters and gradients")
+            st = self.state[p]
+            if len(st) == 0:
+                st["step"] = 0
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            params.append(p)
+        return params
+
+    def build_tables(self):
+        """Host half of a step, callable BEFORE the gradients exist (the tables hold addresses and step sizes only):
+        advances group["step"] like the reference and returns [(lanes, host blob, n_tensors, rows_total)] for the single
+        parameter group HPCS uses (base_hyp_hc.py:143).  Pair with step(tables_dev=...)."""
+        if len(self.param_groups) != 1:
+            raise NotImplementedError("build_tables() serves the single parameter group HPCS configures")
+        group = self.param_groups[0]
+        group.setdefault("step", 0)
+        if group.get("amsgrad", False):
+            raise NotImplementedError("amsgrad is never enabled by HPCS (base_hyp_hc.py:143)")
+        return self._tables(group, self._live_params(group))
+
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, tables=None, tables_dev=None):
+        """tables / tables_dev: what build_tables() returned and the persistent device copies of its blobs (the step
+        driver's parameter block); without them the tables are built and uploaded here."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        if tables is not None:
+            group = self.param_groups[0]
+            b1, b2 = group["betas"]
+            for (lanes, _, n_tensors, rows_total), dev_table in zip(tables, tables_dev):
+                _lib.call("hpcs_radam_step", dev_table, n_tensors, rows_total, lanes, b1, b2, group["eps"],
+                          group["weight_decay"])
+            return loss
         for group in self.param_groups:
             if "step" not in group:
                 group["step"] = 0
             if group.get("amsgrad", False):
                 raise NotImplementedError("amsgrad is never enabled by HPCS (base_hyp_hc.py:143)")
-            params = []
-            for p in group["params"]:
-                if p.grad is None:
-                    continue
-                if p.grad.is_sparse:
-                    raise RuntimeError("Riemannian Adam does not support sparse gradients")
-                if not p.is_cuda:
-                    raise _lib.HpcsNativeError("hpcs_amd.optim.RAdam needs HIP-device parameters (no CPU fallback)")
-                if not (p.is_contiguous() and p.grad.is_contiguous()):
-                    raise _lib.HpcsNativeError("RAdam needs contiguous parameters and gradients")
-                st = self.state[p]
-                if len(st) == 0:
-                    st["step"] = 0
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                params.append(p)
+            params = self._live_params(group)
             if not params:
                 continue
             from .._pinned import upload

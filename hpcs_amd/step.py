@@ -27,9 +27,10 @@ def random_rotations(B, device, generator=None):
     return R.view(B, 3, 3)
 
 
-def rotate_to_channels_first(points, rot=None, seed=0, return_rot=False):
+def rotate_to_channels_first(points, rot=None, seed=0, return_rot=False, seed_dev=None):
     """points [B,N,3] -> [B,3,N] = transpose(points @ R) with one Haar rotation per cloud, in ONE launch
-    (shapenet_hyp_hc.py:63-73).  rot [B,3,3] given: use it; else quaternions from the counter RNG keyed by `seed`."""
+    (shapenet_hyp_hc.py:63-73).  rot [B,3,3] given: use it; else quaternions from the counter RNG keyed by `seed`
+    (or by the device word seed_dev, int64[1], when given)."""
     from . import _lib
     if not points.is_cuda:
         raise _lib.HpcsNativeError("hpcs_amd needs HIP-device tensors (no CPU fallback)")
@@ -38,13 +39,21 @@ def rotate_to_channels_first(points, rot=None, seed=0, return_rot=False):
     x = torch.empty(B, 3, N, device=pts.device, dtype=torch.float32)
     R = torch.empty(B, 3, 3, device=pts.device, dtype=torch.float32) if return_rot else None
     rin = None if rot is None else rot.to(torch.float32).contiguous()
-    _lib.call("hpcs_so3_rotate_points", pts, B, N, int(seed) & (2 ** 63 - 1), rin, x, R)
+    _lib.call("hpcs_so3_rotate_points", pts, B, N, int(seed) & (2 ** 63 - 1), seed_dev, rin, x, R)
     return (x, R) if return_rot else x
 
 
 def to_categorical(y, num_classes):
     """1-hot encode (hpcs/utils/data.py:24-29), on the device of y."""
     return torch.nn.functional.one_hot(y.long(), num_classes).float()
+
+
+class StepCtx:
+    """What the host decided for ONE step before any kernel of it is launched: seeds, the miner's plan, RAdam's tables --
+    already copied into the per-step parameter block (hpcs_amd/_params.py); the fields are the by-value copies and the
+    persistent device views the kernels read."""
+    __slots__ = ("plan", "T_grid", "miner_seed", "rot_seed", "drop_seeds", "seed_dev", "toff_dev", "kk_dev",
+                 "radam_tables", "radam_dev")
 
 
 class HypHCStep(torch.nn.Module):
@@ -68,34 +77,107 @@ class HypHCStep(torch.nn.Module):
         else:
             self.metric_hyp_loss = MetricHyperbolicLoss(cosface=cosface, **common)
         self.lr = lr
-        self._rot_seed = int(torch.initial_seed()) & (2 ** 62 - 1)
+        self._rot_seed = None
         self._rot_calls = 0
         self.side_stream_wgrad = __import__("os").environ.get("HPCS_SIDE_STREAM", "1") != "0"   # 0: serial (profiling)
+        # hipGraph replay of the steady-state step: HPCS_GRAPH = 1 (always), 0 (never) or auto (default: after the warm-up
+        # the step is captured, two eager steps and two replays are timed with events, and the faster mode is kept --
+        # replay wins when the step is launch-bound (small clouds: 2x at B=4, N=256), eager when it is GPU-bound and the
+        # side stream overlaps better than the graph's own scheduling does (B=32, N=1024: replay measured 3.7 % slower)).
+        # Eligible steps: device RNG, miner + fused filter, host copy of the labels given, no caller-supplied rotation /
+        # dropout masks.
+        mode = __import__("os").environ.get("HPCS_GRAPH", "auto").lower()
+        self.use_graph = mode not in ("0", "off", "false")
+        self.graph_auto = mode == "auto"
+        self.graph_warmup = 3               # eager steps before the capture (allocator pools, lazily built tables)
+        self._graph = None
+        self._eager_steps = 0
+        self._tune = None                   # auto mode: {"phase", "t": {"eager": [...], "graph": [...]}, "ev"}
         self.metrics = True
         self.optimizer = None
         self.bucket = None
+        self.params_block = None
+        self.num_class = num_class
 
     def configure(self):
-        """Call once the module is on its device: flat gradient bucket + RAdam over ALL parameters (base_hyp_hc.py:143)."""
+        """Call once the module is on its device: flat gradient bucket + RAdam over ALL parameters (base_hyp_hc.py:143)
+        + the per-step parameter block (seeds, miner plan, RAdam tables: one upload per step)."""
+        from ._params import StepParams
         params = list(self.parameters())
         self.bucket = FlatGradBucket(params)
         self.optimizer = RAdam(params, lr=self.lr)
+        group = self.optimizer.param_groups[0]
+        step0 = group.get("step", 0)
+        tables = self.optimizer.build_tables()            # only to size the block: undo its step-count advance
+        group["step"] = step0
+        self.params_block = StepParams(params[0].device, self.num_class, [t[1].numel() for t in tables])
         return self
 
-    def forward_losses(self, points, label, targets, plan=None, rot=None, drop_masks=None):
-        """points [B,N,3], label [B] category ids, targets [B,N] part ids (all on the device)."""
+    def _next_rot_seed(self):
+        from .miner.triplet_margin_miner import mix64
+        if self._rot_seed is None:
+            import torch.distributed as dist
+            rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+            self._rot_seed = mix64((int(torch.initial_seed()) & (2 ** 64 - 1)) ^ mix64(0xE7037ED1A0B428DB * (rank + 1) & (2 ** 64 - 1)))
+        self._rot_calls += 1            # counter RNG stream: (torch seed at first use, rank, call index), mixed
+        return mix64(self._rot_seed ^ mix64(self._rot_calls)) & (2 ** 63 - 1)
+
+    def _prepare(self, targets_host, own_rotation, own_dropout, T_cap=0):
+        """Host half of a step (before any kernel is launched): plan, seeds, RAdam tables -> parameter block -> ONE
+        asynchronous copy.  Returns the StepCtx the kernels' launchers read."""
+        loss, blk = self.metric_hyp_loss, self.params_block
+        ctx = StepCtx()
+        ctx.plan = None
+        ctx.miner_seed = None
+        ctx.T_grid = 0
+        if targets_host is not None and loss.miner:
+            ctx.plan = loss.make_plan(targets_host, minlength=self.num_class)
+            if ctx.plan.C != self.num_class:
+                raise ValueError(f"labels reach class {ctx.plan.C - 1}, the step was built for {self.num_class} classes")
+            if loss.fused_filter:
+                ctx.miner_seed = loss.hyp_miner.next_seed()
+            ctx.T_grid = max(ctx.plan.T, T_cap)
+        ctx.rot_seed = self._next_rot_seed() if own_rotation else None
+        feat = self.nn_feat
+        ctx.drop_seeds = None
+        if own_dropout and getattr(feat, "dropout", 0.0) > 0.0 and feat.training and hasattr(feat, "next_drop_seed"):
+            ctx.drop_seeds = (feat.next_drop_seed(), feat.next_drop_seed())
+        ctx.radam_tables = self.optimizer.build_tables()
+        blk.begin()
+        blk.put_seeds(rot=ctx.rot_seed or 0, drop1=ctx.drop_seeds[0] if ctx.drop_seeds else 0,
+                      drop2=ctx.drop_seeds[1] if ctx.drop_seeds else 0, miner=ctx.miner_seed or 0)
+        if ctx.plan is not None:
+            blk.put_plan(ctx.plan)
+        blk.put_radam(ctx.radam_tables)
+        blk.commit()
+        ctx.seed_dev, ctx.toff_dev, ctx.kk_dev, ctx.radam_dev = blk.seed_dev, blk.toff_dev, blk.kk_dev, blk.radam_dev
+        return ctx
+
+    def forward_losses(self, points, label, targets, plan=None, rot=None, drop_masks=None, ctx=None):
+        """points [B,N,3], label [B] category ids, targets [B,N] part ids (all on the device).  ctx: the step's StepCtx
+        (training_step); without one the seeds are drawn here and passed by value."""
         if self.train_rotation == "so3":
-            self._rot_calls += 1            # counter RNG stream: (torch seed at configure time, call index)
-            x = rotate_to_channels_first(points, rot=rot, seed=self._rot_seed + self._rot_calls)
+            if ctx is not None and ctx.rot_seed is not None and rot is None:
+                x = rotate_to_channels_first(points, seed=ctx.rot_seed, seed_dev=ctx.seed_dev["rot"])
+            else:
+                x = rotate_to_channels_first(points, rot=rot, seed=0 if rot is not None else self._next_rot_seed())
         else:
             x = points.transpose(2, 1).contiguous().float()
         decode = to_categorical(label, self.num_categories)
-        x_euclidean = self.nn_feat(x, decode) if drop_masks is None else self.nn_feat(x, decode, drop_masks=drop_masks)
+        if drop_masks is not None:
+            x_euclidean = self.nn_feat(x, decode, drop_masks=drop_masks)
+        elif ctx is not None and ctx.drop_seeds is not None:
+            x_euclidean = self.nn_feat(x, decode, drop_seeds=((ctx.drop_seeds[0], ctx.seed_dev["drop1"]),
+                                                              (ctx.drop_seeds[1], ctx.seed_dev["drop2"])))
+        else:
+            x_euclidean = self.nn_feat(x, decode)
         x_poincare = self.nn_emb(x_euclidean) if self.nn_emb is not None else x_euclidean
         xe = x_euclidean.contiguous().view(-1, x_euclidean.shape[-1])
         xp = x_poincare.contiguous().view(-1, x_poincare.shape[-1])
         y = targets.reshape(-1).long()
-        loss = self.metric_hyp_loss.compute_loss(xe, xp, y, plan=plan)
+        if ctx is not None and plan is None:
+            plan = ctx.plan
+        loss = self.metric_hyp_loss.compute_loss(xe, xp, y, plan=plan, step_ctx=ctx)
         out = {"loss_metric": loss["loss_metric"]["losses"],
                "loss_hyp": loss["loss_hyp"]["losses"] * self.trade_off}
         if self.metrics and hasattr(self.metric_hyp_loss, "loss_cosface"):
@@ -122,8 +204,7 @@ class HypHCStep(torch.nn.Module):
         per-cloud best cut, everything on the device; `score` is the batch mean of the best scores (base_hyp_hc.py:241)."""
         from .decode import optimal_k
         if self.test_rotation == "so3":                         # shapenet_hyp_hc.py:58-69
-            self._rot_calls += 1
-            x = rotate_to_channels_first(points, rot=rot, seed=self._rot_seed + self._rot_calls)
+            x = rotate_to_channels_first(points, rot=rot, seed=0 if rot is not None else self._next_rot_seed())
         else:
             x = points.transpose(2, 1).contiguous().float()
         decode = to_categorical(label, self.num_categories)
@@ -142,15 +223,12 @@ class HypHCStep(torch.nn.Module):
                    best_score=best_score, score=best_score.float().mean())
         return out
 
-    def training_step(self, points, label, targets, targets_host=None, rot=None, drop_masks=None):
-        """One optimisation step.  targets_host (CPU copy of the part labels) lets the miner's per-class plan be
-        computed without a device->host sync in the middle of the step."""
-        plan = None
-        if targets_host is not None and self.metric_hyp_loss.miner:
-            plan = self.metric_hyp_loss.make_plan(targets_host)
+    # ---- one optimisation step ------------------------------------------------------------------------------------
+    def _backward_part(self, points, label, targets, ctx, rot, drop_masks):
+        """zero grads -> forward -> losses -> backward (weight gradients on the side stream, joined at the end)."""
         self.bucket.zero()
         zero_arena_reset(points.device)        # one memset for all the step's fp64 accumulators
-        losses = self.forward_losses(points, label, targets, plan=plan, rot=rot, drop_masks=drop_masks)
+        losses = self.forward_losses(points, label, targets, rot=rot, drop_masks=drop_masks, ctx=ctx)
         total = losses["loss_metric"] + losses["loss_hyp"]
         if self.side_stream_wgrad:             # dW GEMMs on a side stream, joined before the all-reduce
             with deferred_weight_grads():
@@ -158,7 +236,128 @@ class HypHCStep(torch.nn.Module):
         else:
             total.backward()
         zero_arena_release()
+        losses["total_loss"] = total
+        # detached: a loss tensor that outlives the step keeps its autograd graph -- and the AccumulateGrad nodes of every
+        # parameter, bound to the stream they were created on -- alive, which breaks a later stream capture
+        return {k_: v.detach() for k_, v in losses.items()}
+
+    def _graph_eligible(self, targets_host, rot, drop_masks):
+        loss = self.metric_hyp_loss
+        return (self.use_graph and targets_host is not None and rot is None and drop_masks is None and loss.miner
+                and loss.fused_filter and loss.hyp_miner.rng == "device" and loss.debug_triplets is None
+                and self.train_rotation in ("so3", None) and self.training)
+
+    def training_step(self, points, label, targets, targets_host=None, rot=None, drop_masks=None):
+        """One optimisation step.  targets_host (CPU copy of the part labels) lets the miner's per-class plan be
+        computed without a device->host sync in the middle of the step -- and makes the step replayable: after
+        `graph_warmup` eager steps the steady-state step is captured ONCE as a hipGraph (forward, losses, backward with
+        its side stream, RAdam; with more than one rank: two graphs around the eager all-reduce) and every later step
+        is: fill the parameter block (host, ~0.1 ms), one upload, one graph launch.  The losses returned by a replayed
+        step are the capture's output tensors, overwritten by every replay."""
+        if self._graph_eligible(targets_host, rot, drop_masks):
+            if self._eager_steps >= self.graph_warmup:
+                if not self.graph_auto:
+                    return self._graphed_step(points, label, targets, targets_host)
+                choice = self._auto_mode()
+                if choice == "graph":
+                    return self._timed(self._graphed_step, points, label, targets, targets_host)
+                if choice == "eager_timed":
+                    return self._timed(self._eager_step, points, label, targets, targets_host)
+            else:
+                self._eager_steps += 1
+        return self._eager_step(points, label, targets, targets_host, rot, drop_masks)
+
+    def _auto_mode(self):
+        """auto mode schedule after the warm-up: capture + first replay (untimed), 2 timed replays, 2 timed eager steps,
+        then the faster mode for good.  Times are event spans of whole steps enqueued back to back."""
+        t = self._tune
+        if t is None:
+            t = self._tune = {"n": 0, "graph": [], "eager": [], "pending": None, "choice": None}
+        if t["choice"] is not None:
+            return t["choice"]
+        self._collect_timing()
+        t["n"] += 1
+        if t["n"] <= 3:
+            t["kind"] = "graph" if t["n"] > 1 else None            # replay 1 also pays the capture: not timed
+            return "graph"
+        if t["n"] <= 5:
+            t["kind"] = "eager"
+            return "eager_timed"
+        g, e = min(t["graph"]), min(t["eager"])
+        t["choice"] = "graph" if g <= e else "eager"
+        t["measured_ms"] = {"graph": g, "eager": e}
+        if t["choice"] == "eager":
+            self.use_graph = False
+        else:
+            self.graph_auto = False
+        return t["choice"]
+
+    def graph_mode(self):
+        """'graph' / 'eager' once decided (or forced), else None while the auto mode is still measuring."""
+        if not self.use_graph:
+            return "eager"
+        if not self.graph_auto:
+            return "graph"
+        return None if self._tune is None or self._tune["choice"] is None else self._tune["choice"]
+
+    def _collect_timing(self):
+        t = self._tune
+        if t["pending"] is not None:
+            kind, e0, e1 = t["pending"]
+            e1.synchronize()
+            if kind is not None:
+                t[kind].append(e0.elapsed_time(e1))
+            t["pending"] = None
+
+    def _timed(self, fn, *args):
+        t = self._tune
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn(*args)
+        e1.record()
+        t["pending"] = (t.get("kind"), e0, e1)
+        return out
+
+    def _eager_step(self, points, label, targets, targets_host, rot=None, drop_masks=None):
+        ctx = self._prepare(targets_host, own_rotation=(self.train_rotation == "so3" and rot is None),
+                            own_dropout=drop_masks is None)
+        losses = self._backward_part(points, label, targets, ctx, rot, drop_masks)
         self.bucket.all_reduce_mean()
-        self.optimizer.step()
-        losses["total_loss"] = total.detach()
+        self.optimizer.step(tables=ctx.radam_tables, tables_dev=ctx.radam_dev)
         return losses
+
+    def _graphed_step(self, points, label, targets, targets_host):
+        import torch.distributed as dist
+        g = self._graph
+        shapes = (tuple(points.shape), tuple(label.shape), tuple(targets.shape), points.dtype, label.dtype, targets.dtype)
+        T_cap = g["T_cap"] if g is not None else 0
+        ctx = self._prepare(targets_host, own_rotation=self.train_rotation == "so3", own_dropout=True, T_cap=T_cap)
+        if g is not None and (g["shapes"] != shapes or ctx.plan.T > g["T_cap"]):
+            g = self._graph = None                           # geometry changed / more triplets than the grid covers
+        if g is None:
+            world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+            g = {"shapes": shapes, "T_cap": int(ctx.plan.T * 1.25) + 1, "world": world,
+                 "in": (points.clone(), label.clone(), targets.clone())}
+            ctx.T_grid = g["T_cap"]
+            torch.cuda.synchronize()
+            g["fwd_bwd"] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g["fwd_bwd"]):
+                g["out"] = self._backward_part(*g["in"], ctx, None, None)
+                if world == 1:
+                    self.optimizer.step(tables=ctx.radam_tables, tables_dev=ctx.radam_dev)
+            if world > 1:
+                g["pool"] = g["fwd_bwd"].pool()
+                g["opt"] = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g["opt"], pool=g["pool"]):
+                    self.optimizer.step(tables=ctx.radam_tables, tables_dev=ctx.radam_dev)
+            self._graph = g
+            # the capture itself executed nothing: fall through to the first replay with this step's parameters
+        for dst, src in zip(g["in"], (points, label, targets)):
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        g["fwd_bwd"].replay()
+        if g["world"] > 1:
+            self.bucket.all_reduce_mean()
+            g["opt"].replay()
+        self.metric_hyp_loss.last_T = ctx.plan.T
+        return g["out"]

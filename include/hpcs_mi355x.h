@@ -148,16 +148,22 @@ int hpcs_edge_grad_reduce(const float* GPD, const int64_t* idx, int B, int Ctot,
  * Y [B,C,L] is the Conv1d output (hpcs_gemm_tn).  slope = 1 means no activation; mask (nullable,
  * [B,C,L]) is the already scaled dropout multiplier.  With mask == NULL and 0 < drop_p < 1 the multiplier is
  * generated in the kernels from a counter hash of (drop_seed, element offset): the same call arguments give the
- * same mask in forward and backward, so it is never stored (nn.Dropout, vn_dgcnn_partseg.py:46,50). */
+ * same mask in forward and backward, so it is never stored (nn.Dropout, vn_dgcnn_partseg.py:46,50).
+ * *_seed_dev (nullable, here and in hpcs_so3_rotate_points / hpcs_hyphc_sampled): when given, the kernel reads the seed
+ * from that device word instead of the by-value argument, so a captured hipGraph can be replayed with a new seed per
+ * step (the step driver refreshes the word with one host->device copy before each replay). */
 int hpcs_bn_stats(const float* Y, int B, int C, int64_t L, double* sums, int sums_zeroed, hpcs_stream_t stream);
 int hpcs_bn_act_fwd(const float* Y, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                    const float* mask, uint64_t drop_seed, float drop_p, int B, int C, int64_t L, float slope, float* out,
+                    const float* mask, uint64_t drop_seed, const uint64_t* drop_seed_dev, float drop_p, int B, int C,
+                    int64_t L, float slope, float* out,
                     hpcs_stream_t stream);
 int hpcs_bn_act_bwd_reduce(const float* Y, const float* gout, const float* mean, const float* rstd,
-                           const float* gamma, const float* beta, const float* mask, uint64_t drop_seed, float drop_p,
+                           const float* gamma, const float* beta, const float* mask, uint64_t drop_seed,
+                           const uint64_t* drop_seed_dev, float drop_p,
                            int B, int C, int64_t L, float slope, double* red, int red_zeroed, hpcs_stream_t stream);
 int hpcs_bn_act_bwd_apply(const float* Y, const float* gout, const float* mean, const float* rstd,
-                          const float* gamma, const float* beta, const float* mask, uint64_t drop_seed, float drop_p,
+                          const float* gamma, const float* beta, const float* mask, uint64_t drop_seed,
+                          const uint64_t* drop_seed_dev, float drop_p,
                           const double* red, int training, int B, int C, int64_t L, float slope, float* gY,
                           hpcs_stream_t stream);
 /* The multiplier tensor that (drop_seed, drop_p) stands for: out[i] = 1/(1-p) or 0 (parity tests). */
@@ -269,12 +275,14 @@ int hpcs_hyphc_bwd(const float* xn, int E, const int64_t* a, const int64_t* p, c
  * (class index, per-class plan, seed) -- no index arrays, no sampler/filter pass -- the margin rule `kind` is applied
  * inline, and loss_sum[1], kept[1] and (gxn != NULL) the UNSCALED gradient gxn [M,E] (accumulated into; caller
  * zero-fills) + gscale[1] come out of one sweep.  Positive-row gradients are accumulated in an LDS table per
- * workgroup.  E must be 16, 32 or 64.  a_dbg/p_dbg/n_dbg (nullable, [T]) receive the generated triplets (tests). */
+ * workgroup.  E must be 16, 32 or 64.  a_dbg/p_dbg/n_dbg (nullable, [T]) receive the generated triplets (tests).
+ * T sizes the grid only and must be >= cls_toff[C], the number of triplets the kernel actually samples (read on the
+ * device): a captured launch sized for the largest batch serves smaller ones, surplus workgroups exit at once. */
 int hpcs_hyphc_sampled(const float* xn, const int64_t* labels, const int32_t* order, const int32_t* offsets,
                        const int64_t* cls_toff, const int32_t* cls_k, int C, int M, int E, int64_t T, uint64_t seed,
-                       const float* scale, float temperature, float margin, int kind, double* loss_sum, int64_t* kept,
-                       float* gxn, double* gscale, int64_t* a_dbg, int64_t* p_dbg, int64_t* n_dbg,
-                       hpcs_stream_t stream);
+                       const uint64_t* seed_dev, const float* scale, float temperature, float margin, int kind,
+                       double* loss_sum, int64_t* kept, float* gxn, double* gscale, int64_t* a_dbg, int64_t* p_dbg,
+                       int64_t* n_dbg, hpcs_stream_t stream);
 /* mean of the M x M similarity in closed form: 0.5 + 0.5*|sum_i xn_i|^2/M^2.  colsum [E] double. */
 int hpcs_colsum(const float* xn, int64_t rows, int E, double* colsum, hpcs_stream_t stream);
 /* cosface: plain CosFace = one level of singleton branches (branch_id NULL, n_levels 1).  Hierarchical CosFace
@@ -330,7 +338,8 @@ int hpcs_radam_step(const hpcs_radam_desc* desc_dev, int n_tensors, int64_t tota
  * One rotation per cloud (pytorch3d random_rotations: normalised Gaussian quaternion; drawn from a counter RNG keyed
  * by `seed`, or taken from rot_in [B,3,3] when given), points [B,N,3] -> x_out [B,3,N] = transpose(points @ R);
  * rot_out [B,3,3] (optional) receives the matrices used. */
-int hpcs_so3_rotate_points(const float* points, int B, int N, uint64_t seed, const float* rot_in, float* x_out,
+int hpcs_so3_rotate_points(const float* points, int B, int N, uint64_t seed, const uint64_t* seed_dev,
+                           const float* rot_in, float* x_out,
                            float* rot_out, hpcs_stream_t stream);
 
 /* ---- next row f4: test-time decode ---------------------------------------------------------------------------------
