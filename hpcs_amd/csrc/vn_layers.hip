@@ -654,8 +654,19 @@ __global__ void vn_bwd_apply_kernel(PdRef pd, const float* __restrict__ gout,
                                     const float* __restrict__ mean, const float* __restrict__ rstd,
                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                     const double* __restrict__ red, int training, int B, int Cout, int Cd, int64_t L,
-                                    int pool_k, float slope, int flags, float* __restrict__ GPD, int c_chunk) {
+                                    int pool_k, float slope, int flags, float* __restrict__ GPD, int c_chunk,
+                                    float* __restrict__ ggamma, float* __restrict__ gbeta) {
     const int Ctot = Cout + Cd;
+    if (ggamma && blockIdx.x == 0 && threadIdx.x == 0) {
+        // BatchNorm parameter gradients are the finished reductions themselves: red = [sum_beta(C) | sum_gamma(C)].  One
+        // writer per channel adds them into the parameters' gradient slots (no separate launches for them).
+        const int c0_ = SHARED ? blockIdx.y * c_chunk : blockIdx.y;
+        const int c1_ = SHARED ? min(Cout, c0_ + c_chunk) : blockIdx.y + 1;
+        for (int c = c0_; c < c1_; ++c) {
+            ggamma[c] += (float)red[Cout + c];
+            gbeta[c] += (float)red[c];
+        }
+    }
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (int64_t)B * L) return;
     const int64_t b = e / L, l = e % L;
@@ -991,9 +1002,13 @@ __global__ void bn_act_bwd_apply_kernel(const float* __restrict__ Y, const float
                                         const float* __restrict__ mask, const double* __restrict__ red, int training,
                                         int B, int C, int64_t L, float slope, float* __restrict__ gY,
                                         unsigned long long dseed, const unsigned long long* __restrict__ dseed_dev,
-                                        unsigned dthr, float dinv) {
+                                        unsigned dthr, float dinv, float* __restrict__ ggamma, float* __restrict__ gbeta) {
     if (dseed_dev) dseed = *dseed_dev;
     const int c = blockIdx.y;
+    if (ggamma && blockIdx.x == 0 && threadIdx.x == 0) {       // red = [sum_beta(C) | sum_gamma(C)]: the parameter gradients
+        ggamma[c] += (float)red[C + c];
+        gbeta[c] += (float)red[c];
+    }
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (int64_t)B * L) return;
     const double count = (double)B * (double)L;
@@ -1948,7 +1963,8 @@ static int vn_bwd_reduce_impl(PdRef pd, const float* gout, const float* mean, co
 
 static int vn_bwd_apply_impl(PdRef pd, const float* gout, const float* mean, const float* rstd, const float* gamma,
                              const float* beta, const double* red, int training, int B, int Cout, int Cd, int pool_k,
-                             float slope, int flags, float* GPD, hipStream_t st) {
+                             float slope, int flags, float* GPD, hipStream_t st, float* ggamma = nullptr,
+                             float* gbeta = nullptr) {
     if (B == 0) return HPCS_OK;
     const int64_t L = pd.L;
     if (Cd == 1 && (flags & HPCS_VN_LRELU)) {
@@ -1960,10 +1976,10 @@ static int vn_bwd_apply_impl(PdRef pd, const float* gout, const float* mean, con
             return HPCS_ERR_HIP;
         hipLaunchKernelGGL((vn_bwd_apply_kernel<true>), dim3(hpcs_cdiv((int64_t)B * L, TPB), hpcs_cdiv(Cout, c_chunk)), dim3(TPB),
                            0, st, pd, gout, mean, rstd, gamma, beta, red, training, B, Cout, Cd, L, pool_k, slope, flags, GPD,
-                           c_chunk);
+                           c_chunk, ggamma, gbeta);
     } else {
         hipLaunchKernelGGL((vn_bwd_apply_kernel<false>), dim3(hpcs_cdiv((int64_t)B * L, TPB), Cout), dim3(TPB), 0, st, pd,
-                           gout, mean, rstd, gamma, beta, red, training, B, Cout, Cd, L, pool_k, slope, flags, GPD, 1);
+                           gout, mean, rstd, gamma, beta, red, training, B, Cout, Cd, L, pool_k, slope, flags, GPD, 1, ggamma, gbeta);
     }
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;
@@ -1992,13 +2008,15 @@ extern "C" int hpcs_vn_bwd_reduce(const float* PD, const float* gout, const floa
 
 extern "C" int hpcs_vn_bwd_apply(const float* PD, const float* gout, const float* mean, const float* rstd,
                                  const float* gamma, const float* beta, const double* red, int training, int B, int Cout,
-                                 int Cd, int64_t L, int pool_k, float slope, int flags, float* GPD, hpcs_stream_t stream) {
+                                 int Cd, int64_t L, int pool_k, float slope, int flags, float* GPD, float* ggamma,
+                                 float* gbeta, hpcs_stream_t stream) {
     int rc = vn_args_ok(PD, mean, rstd, gamma, beta, B, Cout, Cd, L, pool_k, flags);
     if (rc) return rc;
     if (!gout || !GPD) return HPCS_ERR_NULL;
     if ((flags & HPCS_VN_BN) && training && !red) return HPCS_ERR_NULL;
+    if ((ggamma == nullptr) != (gbeta == nullptr) || (ggamma && (!(flags & HPCS_VN_BN) || !red))) return HPCS_ERR_NULL;
     return vn_bwd_apply_impl(PdRef{PD, nullptr, Cout + Cd, L, 0, 0}, gout, mean, rstd, gamma, beta, red, training, B, Cout,
-                             Cd, pool_k, slope, flags, GPD, ST);
+                             Cd, pool_k, slope, flags, GPD, ST, ggamma, gbeta);
 }
 
 static int fused_grid(int B, int64_t L) {
@@ -2202,14 +2220,16 @@ extern "C" int hpcs_bn_act_bwd_reduce(const float* Y, const float* gout, const f
 
 extern "C" int hpcs_bn_act_bwd_apply(const float* Y, const float* gout, const float* mean, const float* rstd,
                                      const float* gamma, const float* beta, const float* mask, uint64_t drop_seed,
-                                     const uint64_t* drop_seed_dev, float drop_p, const double* red, int training, int B, int C, int64_t L, float slope,
-                                     float* gY, hpcs_stream_t stream) {
+                                     const uint64_t* drop_seed_dev, float drop_p, const double* red, int training, int B,
+                                     int C, int64_t L, float slope, float* gY, float* ggamma, float* gbeta,
+                                     hpcs_stream_t stream) {
     if (!Y || !gout || !mean || !rstd || !gamma || !beta || !gY || (training && !red)) return HPCS_ERR_NULL;
+    if ((ggamma == nullptr) != (gbeta == nullptr) || (ggamma && !red)) return HPCS_ERR_NULL;
     if (bad_dims(B, C, L) || C > 65535) return HPCS_ERR_SHAPE;
     if (B == 0) return HPCS_OK;
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(hpcs_cdiv((int64_t)B * L, TPB), C), dim3(TPB), 0, ST, Y, gout, mean,
                        rstd, gamma, beta, mask, red, training, B, C, L, slope, gY, (unsigned long long)drop_seed,
-                       (const unsigned long long*)drop_seed_dev, drop_thresh(drop_p), drop_inv(drop_p));
+                       (const unsigned long long*)drop_seed_dev, drop_thresh(drop_p), drop_inv(drop_p), ggamma, gbeta);
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;
 }

@@ -13,15 +13,29 @@ from . import _lib
 
 
 class FlatGradBucket:
-    def __init__(self, params):
+    def __init__(self, params, adjacent=()):
+        """adjacent: pairs (p, q) of parameters whose gradients should lie back to back in the bucket (q right after p), so
+        that one GEMM can write both -- the feature and direction weights of a VN layer are the two row blocks of ONE
+        stacked weight-gradient GEMM (ops.VNLayerFn).  The layout of the bucket is free: the optimiser walks its own
+        parameter list, the all-reduce sees one flat buffer either way."""
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
         dev = self.params[0].device
         total = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
-        off = 0
+        follower = {id(p): q for p, q in adjacent if p.requires_grad and q.requires_grad}
+        followed = {id(q) for q in follower.values()}
+        order = []
         for p in self.params:
+            if id(p) in followed:
+                continue
+            order.append(p)
+            if id(p) in follower:
+                order.append(follower[id(p)])
+        assert len(order) == len(self.params) and len({id(p) for p in order}) == len(order)
+        off = 0
+        for p in order:
             n = p.numel()
             p.grad = self.flat[off:off + n].view_as(p)
             off += n

@@ -113,13 +113,33 @@ def gemm_WtG(W, G, nb, M, Nc, out=None, accumulate=False):
     return out
 
 
-def gemm_GXt(G, X, nb, M, K, Nc):
-    """dW (M x K) = sum_b G[b] (M x Nc) @ X[b]^T (K x Nc)."""
+def gemm_GXt(G, X, nb, M, K, Nc, out=None):
+    """dW (M x K) = sum_b G[b] (M x Nc) @ X[b]^T (K x Nc).  out: a [M, K] view with unit column stride that the result is
+    ADDED into (a slice of the flat gradient bucket: no temporary, no separate add)."""
     nbytes = call("hpcs_gemm_nt_workspace", M, K, Nc, nb, 1)
     ws = torch.empty(nbytes // 4 + 4, device=G.device, dtype=torch.float32)
+    if out is not None:
+        if tuple(out.shape) != (M, K) or out.stride(1) != 1:
+            raise ValueError("gemm_GXt: out must be an [M, K] view with contiguous rows")
+        call("hpcs_gemm_nt", G, Nc, M * Nc, 0, X, Nc, K * Nc, 0, M, K, Nc, nb, 1, out.data_ptr(), out.stride(0), 1, ws, nbytes)
+        return out
     dW = torch.empty(M, K, device=G.device, dtype=torch.float32)
     call("hpcs_gemm_nt", G, Nc, M * Nc, 0, X, Nc, K * Nc, 0, M, K, Nc, nb, 1, dW, K, 0, ws, nbytes)
     return dW
+
+
+def _stacked_sink(sink_f, sink_d, Cout, Cd, Cin):
+    """One [Cout+Cd, Cin] view over the two gradient slots when they lie back to back in the flat bucket (dp.py lays the
+    feature / direction weights of a VN layer out that way), else None."""
+    if sink_f is None or tuple(sink_f.shape) != (Cout, Cin) or not sink_f.is_contiguous():
+        return None
+    if Cd == 0:
+        return sink_f
+    if sink_d is None or tuple(sink_d.shape) != (Cd, Cin) or not sink_d.is_contiguous():
+        return None
+    if sink_d.data_ptr() != sink_f.data_ptr() + 4 * Cout * Cin or sink_d.untyped_storage().data_ptr() != sink_f.untyped_storage().data_ptr():
+        return None
+    return torch.as_strided(sink_f, (Cout + Cd, Cin), (Cin, 1))
 
 
 # ------------------------------------------------------------------------------------------------ side-stream dW
@@ -161,6 +181,18 @@ def _grad_sink(spec):
     if not (p.is_leaf and p.requires_grad and p.grad is not None and p.grad.is_cuda):
         return None
     return p.grad[index]
+
+
+def _bn_sinks(ctx_params, needs_gamma, needs_beta):
+    """(ggamma_view, gbeta_view) when both BatchNorm parameters take their gradients straight into .grad (inside
+    deferred_weight_grads(): the backward-apply kernels then add them there themselves), else (None, None)."""
+    gamma, beta = ctx_params
+    if not (needs_gamma and needs_beta) or gamma is None or beta is None:
+        return None, None
+    sg, sb = _grad_sink((gamma, ...)), _grad_sink((beta, ...))
+    if sg is None or sb is None or not (sg.is_contiguous() and sb.is_contiguous()):
+        return None, None
+    return sg, sb
 
 
 def _bn_grads(ctx_params, red, C, needs_gamma, needs_beta):
@@ -268,7 +300,9 @@ class ChanMixFn(torch.autograd.Function):
             gx = gx.view_as(x)
         if ctx.needs_input_grad[1]:
             dst = _grad_sink(ctx.sink)
-            if dst is not None:
+            if dst is not None and dst.dim() == 2 and dst.stride(1) == 1:
+                _on_side_stream(lambda: gemm_GXt(g, x, B, M, K, Nc, out=dst), (g, x))     # straight into the bucket
+            elif dst is not None:
                 _on_side_stream(lambda: dst.add_(gemm_GXt(g, x, B, M, K, Nc)), (g, x))
             else:
                 gW = gemm_GXt(g, x, B, M, K, Nc)
@@ -488,8 +522,9 @@ class VNLayerFn(torch.autograd.Function):
             ggamma, gbeta = _bn_grads(ctx.bnparams, red, Cout, ctx.needs_input_grad[3], ctx.needs_input_grad[4])
             return gx, gW, gWd, ggamma, gbeta, None, None, None, None, None, None, None, None
         GPD = torch.empty(B * Ctot * 3 * L, device=dev)
+        sg, sb = _bn_sinks(ctx.bnparams, ctx.needs_input_grad[3], ctx.needs_input_grad[4]) if (flags & VN_BN) else (None, None)
         call("hpcs_vn_bwd_apply", PD, g, mean, rstd, gamma, beta, red, 1 if training else 0, B, Cout, Cd, L, pool_k, slope,
-             flags, GPD)
+             flags, GPD, sg, sb)
         ST = None
         if Cc:
             S = torch.empty(B, Ctot, 3, device=dev)
@@ -538,7 +573,11 @@ class VNLayerFn(torch.autograd.Function):
             Wf_, Wd_ = ctx.wparams
             sink_f = _grad_sink((Wf_, ...)) if ctx.needs_input_grad[1] else None
             sink_d = _grad_sink((Wd_, ...)) if (Cd and ctx.needs_input_grad[2]) else None
-            if (sink_f is not None or not ctx.needs_input_grad[1]) and \
+            both = None if Cc else _stacked_sink(sink_f, sink_d, Cout, Cd, Cin)
+            if both is not None and (sink_d is not None or not Cd):
+                # feature and direction weights lie back to back in the bucket: the stacked GEMM adds straight into them
+                _on_side_stream(lambda: gemm_GXt(GPD, x, B, Ctot, Cin, 3 * L, out=both), (GPD, x))
+            elif (sink_f is not None or not ctx.needs_input_grad[1]) and \
                     (sink_d is not None or not (Cd and ctx.needs_input_grad[2])):
                 def work():
                     gWcat = weight_grads()
@@ -551,7 +590,7 @@ class VNLayerFn(torch.autograd.Function):
                 gWcat = weight_grads()
                 gW = gWcat[:Cout]
                 gWd = gWcat[Cout:] if Cd else None
-        if flags & VN_BN:
+        if (flags & VN_BN) and sg is None:
             ggamma, gbeta = _bn_grads(ctx.bnparams, red, Cout, ctx.needs_input_grad[3], ctx.needs_input_grad[4])
         return gx, gW, gWd, ggamma, gbeta, None, None, None, None, None, None, gxc, None
 
@@ -681,8 +720,9 @@ class VNGraphLayerFn(torch.autograd.Function):
         red = _zeros64(2 * Cout, dev)
         call("hpcs_vn_bwd_reduce", PD, g, mean, rstd, gamma, beta, B, Cout, Cd, L, pool_k, slope, flags, red, 1)
         GPD = torch.empty(B * Ctot * 3 * L, device=dev)
+        sg, sb = _bn_sinks(ctx.bnparams, ctx.needs_input_grad[4], ctx.needs_input_grad[5])
         call("hpcs_vn_bwd_apply", PD, g, mean, rstd, gamma, beta, red, 1 if training else 0, B, Cout, Cd, L, pool_k, slope,
-             flags, GPD)
+             flags, GPD, sg, sb)
         gUV = torch.empty(B, 2 * Ctot, 3, N, device=dev)
         nbytes = call("hpcs_edge_grad_reduce_workspace", B, Ctot, N)
         ws = torch.empty(nbytes // 4, device=dev)
@@ -712,7 +752,8 @@ class VNGraphLayerFn(torch.autograd.Function):
             else:
                 gWcat = weight_grads()
                 gWf, gWd = gWcat[:Cout], gWcat[Cout:]
-        ggamma, gbeta = _bn_grads(ctx.bnparams, red, Cout, ctx.needs_input_grad[4], ctx.needs_input_grad[5])
+        ggamma, gbeta = (None, None) if sg is not None else \
+            _bn_grads(ctx.bnparams, red, Cout, ctx.needs_input_grad[4], ctx.needs_input_grad[5])
         return gfeat, None, gWf, gWd, ggamma, gbeta, None, None, None, None, None
 
 
@@ -778,9 +819,11 @@ class BnActFn(torch.autograd.Function):
         dseed, dp, dsd = ctx.drop
         call("hpcs_bn_act_bwd_reduce", y, g, mean, rstd, gamma, beta, mask, dseed, dsd, dp, B, C, L, slope, red, 1)
         gy = torch.empty_like(y)
+        sg, sb = _bn_sinks(ctx.bnparams, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
         call("hpcs_bn_act_bwd_apply", y, g, mean, rstd, gamma, beta, mask, dseed, dsd, dp, red, 1 if training else 0, B, C, L,
-             slope, gy)
-        ggamma, gbeta = _bn_grads(ctx.bnparams, red, C, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
+             slope, gy, sg, sb)
+        ggamma, gbeta = (None, None) if sg is not None else \
+            _bn_grads(ctx.bnparams, red, C, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
         return gy, ggamma, gbeta, None, None, None, None, None, None
 
 

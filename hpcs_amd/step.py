@@ -104,7 +104,9 @@ class HypHCStep(torch.nn.Module):
         + the per-step parameter block (seeds, miner plan, RAdam tables: one upload per step)."""
         from ._params import StepParams
         params = list(self.parameters())
-        self.bucket = FlatGradBucket(params)
+        pairs = [(m.map_to_feat.weight, m.map_to_dir.weight) for m in self.modules()
+                 if hasattr(m, "map_to_feat") and hasattr(m, "map_to_dir") and hasattr(m, "batchnorm")]
+        self.bucket = FlatGradBucket(params, adjacent=pairs)
         self.optimizer = RAdam(params, lr=self.lr)
         group = self.optimizer.param_groups[0]
         step0 = group.get("step", 0)

@@ -102,9 +102,13 @@ int hpcs_vn_apply_fwd(const float* PD, const float* mean, const float* rstd, con
 int hpcs_vn_bwd_reduce(const float* PD, const float* gout, const float* mean, const float* rstd,
                        const float* gamma, const float* beta, int B, int Cout, int Cd, int64_t L, int pool_k,
                        float slope, int flags, double* red, int red_zeroed, hpcs_stream_t stream);
+/* ggamma / gbeta (nullable, both or neither; here and in hpcs_bn_act_bwd_apply): when given, the BatchNorm parameter
+ * gradients -- the finished reductions red[Cout..2Cout) / red[0..Cout) themselves -- are ADDED into them by the same
+ * launch (one writer per channel), instead of costing two more launches per layer. */
 int hpcs_vn_bwd_apply(const float* PD, const float* gout, const float* mean, const float* rstd,
                       const float* gamma, const float* beta, const double* red, int training, int B, int Cout,
-                      int Cd, int64_t L, int pool_k, float slope, int flags, float* GPD, hpcs_stream_t stream);
+                      int Cd, int64_t L, int pool_k, float slope, int flags, float* GPD, float* ggamma, float* gbeta,
+                      hpcs_stream_t stream);
 /* Fused backward of a BN + VN-LeakyReLU layer with Cd == Cout <= 24 and Cin <= 48 (the EdgeConv layers): the point-wise
  * backward (= hpcs_vn_bwd_apply), the data gradient gX [B,Cin,3,L] = W^T GPD and the weight gradient
  * dW [2*Cout, Cin] (row pitch lddw; added to when dw_accumulate != 0) = sum GPD X^T in ONE pass: GPD stays in LDS.
@@ -165,7 +169,7 @@ int hpcs_bn_act_bwd_apply(const float* Y, const float* gout, const float* mean, 
                           const float* gamma, const float* beta, const float* mask, uint64_t drop_seed,
                           const uint64_t* drop_seed_dev, float drop_p,
                           const double* red, int training, int B, int C, int64_t L, float slope, float* gY,
-                          hpcs_stream_t stream);
+                          float* ggamma, float* gbeta, hpcs_stream_t stream);
 /* The multiplier tensor that (drop_seed, drop_p) stands for: out[i] = 1/(1-p) or 0 (parity tests). */
 int hpcs_dropout_mask(uint64_t drop_seed, float drop_p, int64_t n, float* out, hpcs_stream_t stream);
 
