@@ -35,13 +35,15 @@ __global__ __launch_bounds__(WM* WN * 64, 4) void gemm_tn_kernel(
     const float* __restrict__ At, int lda, const float* __restrict__ Bm, int ldb, int64_t sBo, int64_t sBi,
     float* __restrict__ C, int ldc, int64_t sCo, int64_t sCi, int M, int Nc, int K, int n_inner,
     const float* __restrict__ rowbias, int accumulate, int tilesM, int tilesN, unsigned total, int vecA,
-    int vecB) {
+    int vecB, int vecC) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int A_LD = BK * BM / 4 / NT, B_LD = BK * BN / 4 / NT;
     static_assert(A_LD >= 1 && B_LD >= 1, "tile too small for the thread count");
-    __shared__ float As[2][BK][BM];
-    __shared__ float Bs[2][BK][BN];
+    // one LDS block: the two double-buffered operand tiles, reused as the epilogue's transpose patches
+    __shared__ __attribute__((aligned(16))) float lds_raw[2 * BK * (BM + BN)];
+    float (*As)[BK][BM] = reinterpret_cast<float (*)[BK][BM]>(lds_raw);
+    float (*Bs)[BK][BN] = reinterpret_cast<float (*)[BK][BN]>(lds_raw + 2 * BK * BM);
 
     const unsigned logical = hpcs_xcd_remap(blockIdx.x, total);
     const int rowTile = logical % tilesM;
@@ -132,6 +134,49 @@ __global__ __launch_bounds__(WM* WN * 64, 4) void gemm_tn_kernel(
     }
 
     const float* bias = rowbias ? rowbias + (int64_t)batch * M : nullptr;
+    if (vecC) {
+        // Epilogue through a wave-private LDS patch: the MFMA result holds 4-row x 1-column slivers per lane, i.e. one
+        // dword store per register (two 128-byte row segments per wave instruction).  Transposed through LDS each lane
+        // owns 4 CONSECUTIVE columns instead and the tile leaves as 16-byte stores, eight 128-byte row segments per
+        // instruction -- the shape that streams at the HBM rate (the EdgeConv mixes write 330 MB per launch).
+        constexpr int PP = 36;                                   // patch pitch: 16-byte aligned rows, conflict-free
+        static_assert(2 * BK * (BM + BN) >= NT / 64 * 32 * PP, "patch does not fit");
+        float* patch = lds_raw + wave * (32 * PP);
+        // (the main loop ended with a barrier: nobody reads As / Bs any more)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row0 = m0 + wm * (BM / WM) + i * 32, col0 = n0 + wn * (BN / WN) + j * 32;
+                if (row0 >= M || col0 >= Nc) continue;           // wave-uniform
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    patch[((r & 3) + 8 * (r >> 2) + 4 * lk) * PP + lr] = acc[i][j][r];
+                __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0); the patch is wave-private: no barrier
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int rr = it * 8 + (lane >> 3), c4 = (lane & 7) * 4;
+                    const int row = row0 + rr, col = col0 + c4;
+                    if (row < M && col < Nc) {
+                        float4 v = *reinterpret_cast<const float4*>(patch + rr * PP + c4);
+                        if (bias) { const float bb = bias[row]; v.x += bb; v.y += bb; v.z += bb; v.w += bb; }
+                        float* dst = Cp + (int64_t)row * ldc + col;
+                        if (col + 3 < Nc) {
+                            if (accumulate) {
+                                const float4 o = *reinterpret_cast<const float4*>(dst);
+                                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                            }
+                            *reinterpret_cast<float4*>(dst) = v;
+                        } else {
+                            const float vv[4] = {v.x, v.y, v.z, v.w};
+                            for (int q = 0; q < 4 && col + q < Nc; ++q) dst[q] = accumulate ? dst[q] + vv[q] : vv[q];
+                        }
+                    }
+                }
+                __builtin_amdgcn_s_waitcnt(0xC07F);              // the reads are done before the next tile overwrites
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -574,6 +619,9 @@ extern "C" int hpcs_gemm_tn(const float* At, int lda, const float* Bm, int ldb, 
     hipStream_t st = (hipStream_t)stream;
     const int vecA = (lda % 4 == 0) && aligned16(At);
     const int vecB = (ldb % 4 == 0) && (strideB_o % 4 == 0) && (strideB_i % 4 == 0) && aligned16(Bm);
+    static int vecC_env = -1;
+    if (vecC_env < 0) { const char* e = getenv("HPCS_GEMM_VECSTORE"); vecC_env = e ? atoi(e) != 0 : 1; }
+    const int vecC = vecC_env && (ldc % 4 == 0) && (strideC_o % 4 == 0) && (strideC_i % 4 == 0) && aligned16(C);
     const int nb = n_outer * n_inner;
     {   // fewer than 32 tiles of 128x128 over all batches and a short enough reduction: the per-element kernel
         const long tiles = (long)hpcs_cdiv(M, 128) * hpcs_cdiv(Nc, 128) * nb;
@@ -594,7 +642,7 @@ extern "C" int hpcs_gemm_tn(const float* At, int lda, const float* Bm, int ldb, 
         if (total > 0x7fffffffL) return HPCS_ERR_UNSUPPORTED;
         hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, BK, 2, 2>), dim3((unsigned)total), dim3(256), 0, st, At, lda, Bm,
                            ldb, strideB_o, strideB_i, C, ldc, strideC_o, strideC_i, M, Nc, K, n_inner, rowbias,
-                           accumulate, tm, tn, (unsigned)total, vecA, vecB);
+                           accumulate, tm, tn, (unsigned)total, vecA, vecB, vecC);
     } else {
         constexpr int BM = 64, BN = 128, BK = 16;
         const int tm = hpcs_cdiv(M, BM), tn = hpcs_cdiv(Nc, BN);
@@ -602,7 +650,7 @@ extern "C" int hpcs_gemm_tn(const float* At, int lda, const float* Bm, int ldb, 
         if (total > 0x7fffffffL) return HPCS_ERR_UNSUPPORTED;
         hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, BK, 1, 4>), dim3((unsigned)total), dim3(256), 0, st, At, lda, Bm,
                            ldb, strideB_o, strideB_i, C, ldc, strideC_o, strideC_i, M, Nc, K, n_inner, rowbias,
-                           accumulate, tm, tn, (unsigned)total, vecA, vecB);
+                           accumulate, tm, tn, (unsigned)total, vecA, vecB, vecC);
     }
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;
