@@ -87,3 +87,12 @@ def broadcast_parameters(module, src=0):
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src=src)
+
+
+def broadcast_buffers(module, src=0):
+    """Re-synchronise the BatchNorm running statistics from rank `src` (what DDP's broadcast_buffers=True does every
+    forward; the step driver keeps them per-replica between calls -- call this before a checkpoint or an evaluation)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    for t in module.buffers():
+        dist.broadcast(t.data, src=src)
