@@ -258,15 +258,30 @@ __device__ __forceinline__ void load3(const float* __restrict__ base, int64_t L,
 //                    POINT-level products U = W_a F, V = (W_b - W_a) F (a GEMM k times smaller than the edge GEMM) and
 //                    PD[b,ch,:,n*k+j] = U[b,ch,:,idx[b,n,j]] + V[b,ch,:,n] is formed on the fly; neither the
 //                    [B,2C,3,N,k] edge tensor (vn_dgcnn_util.py:33-39) nor PD ever reaches HBM.
+//   w2 != nullptr  : TWO-input-channel layer (conv1: its input is the coordinate edge feature [B,2,3,L]).  base = that
+//                    edge tensor, w2 = the stacked weight [Ctot] rows of pitch ldw, and PD[b,ch,a,l] = fma(w[ch][1], E1, w[ch][0] * E0)
+//                    -- the k-ordered fma chain the MFMA GEMM evaluates, bit for bit -- is formed on the fly: the 330 MB PD of
+//                    conv1 (42 channels out of 2) is never written nor read (5 passes over it per step).
 struct PdRef {
     const float* base;
     const int64_t* idx;
     int Ctot;
     int64_t L;
     int N, k;
+    const float* w2 = nullptr;
+    int ldw = 0;
 };
+__host__ __device__ __forceinline__ bool pd_materialised(const PdRef& r) { return r.idx == nullptr && r.w2 == nullptr; }
 
 __device__ __forceinline__ void pd_load3(const PdRef& r, int64_t b, int ch, int64_t l, float (&v)[3]) {
+    if (r.w2 != nullptr) {
+        const float w0 = r.w2[(int64_t)ch * r.ldw], w1 = r.w2[(int64_t)ch * r.ldw + 1];
+        const float* e0 = r.base + ((b * 2 + 0) * 3) * r.L + l;
+        const float* e1 = r.base + ((b * 2 + 1) * 3) * r.L + l;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) v[a] = __fmaf_rn(w1, e1[(int64_t)a * r.L], __fmul_rn(w0, e0[(int64_t)a * r.L]));
+        return;
+    }
     if (r.idx == nullptr) {
         load3(r.base + ((b * r.Ctot + ch) * 3) * r.L + l, r.L, v);
         return;
@@ -310,23 +325,45 @@ __global__ void vn_norm_stats_kernel(PdRef pd, int B, int Ctot, int64_t L, int C
 // (cloud, channel) row with 16-byte loads and no index arithmetic per element (the scalar kernel above pays a 64-bit
 // division per element and ran at ~2 TB/s).
 constexpr int VEC_ITEMS = 2;
+// K2: PD = w2[c] . E (two input channels, PdRef::w2) formed on the fly: `PD` then points at E [B,2,3,L].
+__device__ __forceinline__ void k2_vec(const float* __restrict__ E, int64_t b, int a, int64_t L, int64_t l, float w0, float w1,
+                                       float (&o)[4]) {
+    const float4 e0 = *reinterpret_cast<const float4*>(E + ((b * 2 + 0) * 3 + a) * L + l);
+    const float4 e1 = *reinterpret_cast<const float4*>(E + ((b * 2 + 1) * 3 + a) * L + l);
+    o[0] = __fmaf_rn(w1, e1.x, __fmul_rn(w0, e0.x));
+    o[1] = __fmaf_rn(w1, e1.y, __fmul_rn(w0, e0.y));
+    o[2] = __fmaf_rn(w1, e1.z, __fmul_rn(w0, e0.z));
+    o[3] = __fmaf_rn(w1, e1.w, __fmul_rn(w0, e0.w));
+}
+template <bool K2>
 __global__ __launch_bounds__(TPB) void vn_norm_stats_vec_kernel(const float* __restrict__ PD, int Ctot, int64_t L, int Cout,
-                                                               double* __restrict__ sums) {
+                                                               double* __restrict__ sums, const float* __restrict__ w2, int ldw) {
     __shared__ double red[16];
     const int c = blockIdx.y, b = blockIdx.z;
     const float* base = PD + (((int64_t)b * Ctot + c) * 3) * L;
+    const float w0 = K2 ? w2[(int64_t)c * ldw] : 0.f, w1 = K2 ? w2[(int64_t)c * ldw + 1] : 0.f;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int it = 0; it < VEC_ITEMS; ++it) {
         const int64_t l = ((int64_t)blockIdx.x * VEC_ITEMS + it) * (TPB * 4) + threadIdx.x * 4;
         if (l < L) {
-            const float4 x = *reinterpret_cast<const float4*>(base + l);
-            const float4 y = *reinterpret_cast<const float4*>(base + L + l);
-            const float4 z = *reinterpret_cast<const float4*>(base + 2 * L + l);
-            const float n0 = sqrtf(x.x * x.x + y.x * y.x + z.x * z.x) + VN_EPS;
-            const float n1 = sqrtf(x.y * x.y + y.y * y.y + z.y * z.y) + VN_EPS;
-            const float n2 = sqrtf(x.z * x.z + y.z * y.z + z.z * z.z) + VN_EPS;
-            const float n3 = sqrtf(x.w * x.w + y.w * y.w + z.w * z.w) + VN_EPS;
+            float px[4], py[4], pz[4];
+            if (K2) {
+                k2_vec(PD, b, 0, L, l, w0, w1, px);
+                k2_vec(PD, b, 1, L, l, w0, w1, py);
+                k2_vec(PD, b, 2, L, l, w0, w1, pz);
+            } else {
+                const float4 x = *reinterpret_cast<const float4*>(base + l);
+                const float4 y = *reinterpret_cast<const float4*>(base + L + l);
+                const float4 z = *reinterpret_cast<const float4*>(base + 2 * L + l);
+                px[0] = x.x; px[1] = x.y; px[2] = x.z; px[3] = x.w;
+                py[0] = y.x; py[1] = y.y; py[2] = y.z; py[3] = y.w;
+                pz[0] = z.x; pz[1] = z.y; pz[2] = z.z; pz[3] = z.w;
+            }
+            const float n0 = sqrtf(px[0] * px[0] + py[0] * py[0] + pz[0] * pz[0]) + VN_EPS;
+            const float n1 = sqrtf(px[1] * px[1] + py[1] * py[1] + pz[1] * pz[1]) + VN_EPS;
+            const float n2 = sqrtf(px[2] * px[2] + py[2] * py[2] + pz[2] * pz[2]) + VN_EPS;
+            const float n3 = sqrtf(px[3] * px[3] + py[3] * py[3] + pz[3] * pz[3]) + VN_EPS;
             s1 += (n0 + n1) + (n2 + n3);
             s2 += (n0 * n0 + n1 * n1) + (n2 * n2 + n3 * n3);
         }
@@ -418,12 +455,12 @@ __global__ void vn_apply_pool_fwd_kernel(PdRef pd, const float* __restrict__ mea
                     const float4 v = *reinterpret_cast<const float4*>(dp + a * L + j);
                     dv[a][0] = v.x; dv[a][1] = v.y; dv[a][2] = v.z; dv[a][3] = v.w;
                 }
-            } else if (pd.idx == nullptr) {
+            } else if (pd_materialised(pd)) {
                 pv[a][0] = pp[a * L + j];
                 if (act) dv[a][0] = dp[a * L + j];
             }
         }
-        if (!VEC && pd.idx != nullptr) {
+        if (!VEC && !pd_materialised(pd)) {
             float t3[3];
             pd_load3(pd, b, c, n * pool_k + j, t3);
             pv[0][0] = t3[0]; pv[1][0] = t3[1]; pv[2][0] = t3[2];
@@ -578,17 +615,20 @@ __global__ void vn_bwd_reduce_kernel(PdRef pd, const float* __restrict__ gout,
 
 // Vector form of the backward reduction (materialised layout, L % 4 == 0; pooled layers need pool_k % 4 == 0 so the four
 // positions of a lane belong to one point).
+template <bool K2>
 __global__ __launch_bounds__(TPB) void vn_bwd_reduce_vec_kernel(const float* __restrict__ PD, const float* __restrict__ gout,
                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                int Cout, int Cd, int64_t L, int pool_k, float slope, int flags,
-                                                               double* __restrict__ red_out) {
+                                                               double* __restrict__ red_out, const float* __restrict__ w2, int ldw) {
     __shared__ double red[16];
     const int c = blockIdx.y, b = blockIdx.z;
     const int Ctot = Cout + Cd;
     const int cd = Cd == 1 ? Cout : Cout + c;
     const bool act = flags & HPCS_VN_LRELU;
     const float mu = mean[c], rs = rstd[c], ga = gamma[c], be = beta[c];
+    const float wp0 = K2 ? w2[(int64_t)c * ldw] : 0.f, wp1 = K2 ? w2[(int64_t)c * ldw + 1] : 0.f;
+    const float wd0 = K2 ? w2[(int64_t)cd * ldw] : 0.f, wd1 = K2 ? w2[(int64_t)cd * ldw + 1] : 0.f;
     const float* pp = PD + (((int64_t)b * Ctot + c) * 3) * L;
     const float* dp = PD + (((int64_t)b * Ctot + cd) * 3) * L;
     float s1 = 0.f, s2 = 0.f;
@@ -599,11 +639,16 @@ __global__ __launch_bounds__(TPB) void vn_bwd_reduce_vec_kernel(const float* __r
             float pv[3][4], dv[3][4], gv[3][4];
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
-                const float4 u = *reinterpret_cast<const float4*>(pp + a * L + l);
-                pv[a][0] = u.x; pv[a][1] = u.y; pv[a][2] = u.z; pv[a][3] = u.w;
-                if (act) {
-                    const float4 v = *reinterpret_cast<const float4*>(dp + a * L + l);
-                    dv[a][0] = v.x; dv[a][1] = v.y; dv[a][2] = v.z; dv[a][3] = v.w;
+                if (K2) {
+                    k2_vec(PD, b, a, L, l, wp0, wp1, pv[a]);
+                    if (act) k2_vec(PD, b, a, L, l, wd0, wd1, dv[a]);
+                } else {
+                    const float4 u = *reinterpret_cast<const float4*>(pp + a * L + l);
+                    pv[a][0] = u.x; pv[a][1] = u.y; pv[a][2] = u.z; pv[a][3] = u.w;
+                    if (act) {
+                        const float4 v = *reinterpret_cast<const float4*>(dp + a * L + l);
+                        dv[a][0] = v.x; dv[a][1] = v.y; dv[a][2] = v.z; dv[a][3] = v.w;
+                    }
                 }
             }
             if (pool_k > 0) {
@@ -1877,9 +1922,13 @@ extern "C" int hpcs_edge_gather_bwd(const float* gout, const int64_t* idx, int B
 static int vn_norm_stats_impl(PdRef pd, int B, int Cout, double* sums, int zeroed, hipStream_t st) {
     if (!zeroed && hipMemsetAsync(sums, 0, sizeof(double) * 2 * Cout, st) != hipSuccess) return HPCS_ERR_HIP;
     if (B == 0) return HPCS_OK;
-    if (pd.idx == nullptr && pd.L % 4 == 0 && (((uintptr_t)pd.base & 15u) == 0) && B <= 65535 && Cout <= 65535)
-        hipLaunchKernelGGL(vn_norm_stats_vec_kernel, dim3(hpcs_cdiv(pd.L, TPB * 4 * VEC_ITEMS), Cout, B), dim3(TPB), 0, st, pd.base,
-                           pd.Ctot, pd.L, Cout, sums);
+    const bool vec_ok = pd.idx == nullptr && pd.L % 4 == 0 && (((uintptr_t)pd.base & 15u) == 0) && B <= 65535 && Cout <= 65535;
+    if (vec_ok && pd.w2 == nullptr)
+        hipLaunchKernelGGL(vn_norm_stats_vec_kernel<false>, dim3(hpcs_cdiv(pd.L, TPB * 4 * VEC_ITEMS), Cout, B), dim3(TPB), 0, st,
+                           pd.base, pd.Ctot, pd.L, Cout, sums, (const float*)nullptr, 0);
+    else if (vec_ok)
+        hipLaunchKernelGGL(vn_norm_stats_vec_kernel<true>, dim3(hpcs_cdiv(pd.L, TPB * 4 * VEC_ITEMS), Cout, B), dim3(TPB), 0, st,
+                           pd.base, pd.Ctot, pd.L, Cout, sums, pd.w2, pd.ldw);
     else
         hipLaunchKernelGGL(vn_norm_stats_kernel, dim3(hpcs_cdiv((int64_t)B * pd.L, TPB * ITEMS), Cout), dim3(TPB), 0, st, pd, B,
                            pd.Ctot, pd.L, Cout, sums);
@@ -1924,7 +1973,7 @@ static int vn_apply_fwd_impl(PdRef pd, const float* mean, const float* rstd, con
                              int Cout, int Cd, int pool_k, float slope, int flags, float* out, hipStream_t st) {
     const int64_t L = pd.L;
     if (pool_k > 0) {
-        const bool vec = pd.idx == nullptr && (pool_k % 4 == 0) && (L % 4 == 0) && (((uintptr_t)pd.base & 15u) == 0);
+        const bool vec = pd_materialised(pd) && (pool_k % 4 == 0) && (L % 4 == 0) && (((uintptr_t)pd.base & 15u) == 0);
         const dim3 grid(hpcs_cdiv((int64_t)B * (L / pool_k), 64), Cout);
         if (vec && pool_k <= 64 && B <= 65535 && Cout <= 65535)
             hipLaunchKernelGGL(vn_apply_pool_tile_kernel, dim3(hpcs_cdiv(L / pool_k, 64), Cout, B), dim3(16 * pool_k), 0, st,
@@ -1951,9 +2000,12 @@ static int vn_bwd_reduce_impl(PdRef pd, const float* gout, const float* mean, co
     if (B == 0) return HPCS_OK;
     const bool vec = pd.idx == nullptr && pd.L % 4 == 0 && (((uintptr_t)pd.base & 15u) == 0) && B <= 65535 && Cout <= 65535 &&
                      (pool_k > 0 ? pool_k % 4 == 0 : (((uintptr_t)gout & 15u) == 0));
-    if (vec)
-        hipLaunchKernelGGL(vn_bwd_reduce_vec_kernel, dim3(hpcs_cdiv(pd.L, TPB * 4 * VEC_ITEMS), Cout, B), dim3(TPB), 0, st, pd.base,
-                           gout, mean, rstd, gamma, beta, Cout, Cd, pd.L, pool_k, slope, flags, red);
+    if (vec && pd.w2 == nullptr)
+        hipLaunchKernelGGL(vn_bwd_reduce_vec_kernel<false>, dim3(hpcs_cdiv(pd.L, TPB * 4 * VEC_ITEMS), Cout, B), dim3(TPB), 0, st,
+                           pd.base, gout, mean, rstd, gamma, beta, Cout, Cd, pd.L, pool_k, slope, flags, red, (const float*)nullptr, 0);
+    else if (vec)
+        hipLaunchKernelGGL(vn_bwd_reduce_vec_kernel<true>, dim3(hpcs_cdiv(pd.L, TPB * 4 * VEC_ITEMS), Cout, B), dim3(TPB), 0, st,
+                           pd.base, gout, mean, rstd, gamma, beta, Cout, Cd, pd.L, pool_k, slope, flags, red, pd.w2, pd.ldw);
     else
         hipLaunchKernelGGL(vn_bwd_reduce_kernel, dim3(hpcs_cdiv((int64_t)B * pd.L, TPB * ITEMS), Cout), dim3(TPB), 0, st, pd, gout,
                            mean, rstd, gamma, beta, B, Cout, Cd, pd.L, pool_k, slope, flags, red);
@@ -2017,6 +2069,69 @@ extern "C" int hpcs_vn_bwd_apply(const float* PD, const float* gout, const float
     if ((ggamma == nullptr) != (gbeta == nullptr) || (ggamma && (!(flags & HPCS_VN_BN) || !red))) return HPCS_ERR_NULL;
     return vn_bwd_apply_impl(PdRef{PD, nullptr, Cout + Cd, L, 0, 0}, gout, mean, rstd, gamma, beta, red, training, B, Cout,
                              Cd, pool_k, slope, flags, GPD, ST, ggamma, gbeta);
+}
+
+// ---- two-input-channel layers (conv1): PD = W E formed on the fly from the edge tensor E [B,2,3,L] and the stacked weight
+// W2 [Cout+Cd rows, pitch ldw >= 2] (PdRef::w2); same kernels, same point-wise code, bit-identical values.
+static int k2_args_ok(const void* E, const void* W2, int ldw) { return (!E || !W2) ? HPCS_ERR_NULL : (ldw < 2 ? HPCS_ERR_SHAPE : HPCS_OK); }
+
+extern "C" int hpcs_vn_norm_stats_k2(const float* E, const float* W2, int ldw, int B, int Cout, int Ctot, int64_t L,
+                                     double* sums, int sums_zeroed, hpcs_stream_t stream) {
+    int rc = k2_args_ok(E, W2, ldw);
+    if (rc) return rc;
+    if (!sums) return HPCS_ERR_NULL;
+    if (bad_dims(B, Cout, L) || Ctot < Cout) return HPCS_ERR_SHAPE;
+    PdRef pd{E, nullptr, Ctot, L, 0, 0};
+    pd.w2 = W2;
+    pd.ldw = ldw;
+    return vn_norm_stats_impl(pd, B, Cout, sums, sums_zeroed, ST);
+}
+
+extern "C" int hpcs_vn_apply_fwd_k2(const float* E, const float* W2, int ldw, const float* mean, const float* rstd,
+                                    const float* gamma, const float* beta, int B, int Cout, int Cd, int64_t L, int pool_k,
+                                    float slope, int flags, float* out, hpcs_stream_t stream) {
+    int rc = k2_args_ok(E, W2, ldw);
+    if (rc) return rc;
+    rc = vn_args_ok(E, mean, rstd, gamma, beta, B, Cout, Cd, L, pool_k, flags);
+    if (rc) return rc;
+    if (!out) return HPCS_ERR_NULL;
+    PdRef pd{E, nullptr, Cout + Cd, L, 0, 0};
+    pd.w2 = W2;
+    pd.ldw = ldw;
+    return vn_apply_fwd_impl(pd, mean, rstd, gamma, beta, B, Cout, Cd, pool_k, slope, flags, out, ST);
+}
+
+extern "C" int hpcs_vn_bwd_reduce_k2(const float* E, const float* W2, int ldw, const float* gout, const float* mean,
+                                     const float* rstd, const float* gamma, const float* beta, int B, int Cout, int Cd,
+                                     int64_t L, int pool_k, float slope, int flags, double* red, int red_zeroed,
+                                     hpcs_stream_t stream) {
+    int rc = k2_args_ok(E, W2, ldw);
+    if (rc) return rc;
+    rc = vn_args_ok(E, mean, rstd, gamma, beta, B, Cout, Cd, L, pool_k, flags);
+    if (rc) return rc;
+    if (!gout || !red) return HPCS_ERR_NULL;
+    PdRef pd{E, nullptr, Cout + Cd, L, 0, 0};
+    pd.w2 = W2;
+    pd.ldw = ldw;
+    return vn_bwd_reduce_impl(pd, gout, mean, rstd, gamma, beta, B, Cout, Cd, pool_k, slope, flags, red, red_zeroed, ST);
+}
+
+extern "C" int hpcs_vn_bwd_apply_k2(const float* E, const float* W2, int ldw, const float* gout, const float* mean,
+                                    const float* rstd, const float* gamma, const float* beta, const double* red,
+                                    int training, int B, int Cout, int Cd, int64_t L, int pool_k, float slope, int flags,
+                                    float* GPD, float* ggamma, float* gbeta, hpcs_stream_t stream) {
+    int rc = k2_args_ok(E, W2, ldw);
+    if (rc) return rc;
+    rc = vn_args_ok(E, mean, rstd, gamma, beta, B, Cout, Cd, L, pool_k, flags);
+    if (rc) return rc;
+    if (!gout || !GPD) return HPCS_ERR_NULL;
+    if ((flags & HPCS_VN_BN) && training && !red) return HPCS_ERR_NULL;
+    if ((ggamma == nullptr) != (gbeta == nullptr) || (ggamma && (!(flags & HPCS_VN_BN) || !red))) return HPCS_ERR_NULL;
+    PdRef pd{E, nullptr, Cout + Cd, L, 0, 0};
+    pd.w2 = W2;
+    pd.ldw = ldw;
+    return vn_bwd_apply_impl(pd, gout, mean, rstd, gamma, beta, red, training, B, Cout, Cd, pool_k, slope, flags, GPD, ST,
+                             ggamma, gbeta);
 }
 
 static int fused_grid(int B, int64_t L) {

@@ -14,6 +14,8 @@ VN_BN, VN_LRELU = 1, 2
 # 150 + 180 + 230 us with the weight gradient on the side stream): opt-in, tested equal.
 FUSED_EDGE_BACKWARD = bool(__import__("os").environ.get("HPCS_FUSED_BWD"))
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+# conv1 (two input channels) forms its pre-activations inside the point-wise kernels instead of materialising them
+K2_ON_THE_FLY = __import__("os").environ.get("HPCS_K2", "1") != "0"
 
 
 def _need_cuda(*ts):
@@ -693,20 +695,31 @@ class VNGraphLayerFn(torch.autograd.Function):
         E = torch.empty(B, 2 * C, 3, N, k, device=dev, dtype=torch.float32)
         call("hpcs_edge_gather_fwd", feat, idx, B, C, N, k, E)
         WxP = PreparedW(Wf, Wd)
-        PD = gemm_WX(WxP, E, B, 2 * C, 3 * L)
-        del E
+        flags = VN_BN | VN_LRELU
         mean = torch.empty(Cout, device=dev)
         rstd = torch.empty(Cout, device=dev)
-        sums = None
-        if training:
-            sums = _zeros64(2 * Cout, dev)
-            call("hpcs_vn_norm_stats", PD, B, Cout, Ctot, L, sums, 1)
+        sums = _zeros64(2 * Cout, dev) if training else None
+        k2 = C == 1 and K2_ON_THE_FLY
+        if k2:
+            # two input channels (conv1): PD = W E is two fmas per value -- formed inside the point-wise kernels from the
+            # 16 MB edge tensor, bit-identical to the GEMM's chain, instead of a 330 MB tensor written once and read 4 times
+            PD, ldw = E, WxP.Wp.shape[1]
+            if training:
+                call("hpcs_vn_norm_stats_k2", E, WxP.Wp, ldw, B, Cout, Ctot, L, sums, 1)
+        else:
+            PD = gemm_WX(WxP, E, B, 2 * C, 3 * L)
+            del E
+            if training:
+                call("hpcs_vn_norm_stats", PD, B, Cout, Ctot, L, sums, 1)
         call("hpcs_bn_finalize", sums, Cout, B * L, BN_EPS, BN_MOMENTUM, rmean, rvar, mean, rstd, 1 if training else 0)
         out = torch.empty((B, Cout, 3, N) if pool_k else (B, Cout, 3, N, k), device=dev)
-        flags = VN_BN | VN_LRELU
-        call("hpcs_vn_apply_fwd", PD, mean, rstd, gamma, beta, B, Cout, Cd, L, pool_k, slope, flags, out)
+        if k2:
+            call("hpcs_vn_apply_fwd_k2", PD, WxP.Wp, ldw, mean, rstd, gamma, beta, B, Cout, Cd, L, pool_k, slope, flags, out)
+        else:
+            call("hpcs_vn_apply_fwd", PD, mean, rstd, gamma, beta, B, Cout, Cd, L, pool_k, slope, flags, out)
         ctx.save_for_backward(feat, idx, WxP.Wp, PD, mean, rstd, gamma, beta)
         ctx.cfg = (B, C, N, k, Cout, Cd, pool_k, slope, flags, bool(training))
+        ctx.k2 = k2
         return out
 
     @staticmethod
@@ -718,11 +731,17 @@ class VNGraphLayerFn(torch.autograd.Function):
         g = _f32c(g)
         dev = g.device
         red = _zeros64(2 * Cout, dev)
-        call("hpcs_vn_bwd_reduce", PD, g, mean, rstd, gamma, beta, B, Cout, Cd, L, pool_k, slope, flags, red, 1)
         GPD = torch.empty(B * Ctot * 3 * L, device=dev)
         sg, sb = _bn_sinks(ctx.bnparams, ctx.needs_input_grad[4], ctx.needs_input_grad[5])
-        call("hpcs_vn_bwd_apply", PD, g, mean, rstd, gamma, beta, red, 1 if training else 0, B, Cout, Cd, L, pool_k, slope,
-             flags, GPD, sg, sb)
+        if ctx.k2:                    # PD is the edge tensor E: pre-activations re-formed on the fly (see forward)
+            ldw = Wp.shape[1]
+            call("hpcs_vn_bwd_reduce_k2", PD, Wp, ldw, g, mean, rstd, gamma, beta, B, Cout, Cd, L, pool_k, slope, flags, red, 1)
+            call("hpcs_vn_bwd_apply_k2", PD, Wp, ldw, g, mean, rstd, gamma, beta, red, 1 if training else 0, B, Cout, Cd, L,
+                 pool_k, slope, flags, GPD, sg, sb)
+        else:
+            call("hpcs_vn_bwd_reduce", PD, g, mean, rstd, gamma, beta, B, Cout, Cd, L, pool_k, slope, flags, red, 1)
+            call("hpcs_vn_bwd_apply", PD, g, mean, rstd, gamma, beta, red, 1 if training else 0, B, Cout, Cd, L, pool_k, slope,
+                 flags, GPD, sg, sb)
         gUV = torch.empty(B, 2 * Ctot, 3, N, device=dev)
         nbytes = call("hpcs_edge_grad_reduce_workspace", B, Ctot, N)
         ws = torch.empty(nbytes // 4, device=dev)

@@ -245,6 +245,13 @@ class HypHCStep(torch.nn.Module):
 
     def _graph_eligible(self, targets_host, rot, drop_masks):
         loss = self.metric_hyp_loss
+        if self.use_graph and self.graph_auto and self._graph is None and self._tune is None:
+            # auto mode never captures under a multi-rank process group: stream capture beside RCCL's watchdog / proxy
+            # threads has not run on hardware here (the world-2 test drives the two-graph path with gloo, HPCS_GRAPH=1),
+            # and the multi-GPU step is GPU-bound, where eager measured faster anyway
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                self.use_graph = False
         return (self.use_graph and targets_host is not None and rot is None and drop_masks is None and loss.miner
                 and loss.fused_filter and loss.hyp_miner.rng == "device" and loss.debug_triplets is None
                 and self.train_rotation in ("so3", None) and self.training)
@@ -343,14 +350,14 @@ class HypHCStep(torch.nn.Module):
             ctx.T_grid = g["T_cap"]
             torch.cuda.synchronize()
             g["fwd_bwd"] = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g["fwd_bwd"]):
+            with torch.cuda.graph(g["fwd_bwd"], capture_error_mode="thread_local"):
                 g["out"] = self._backward_part(*g["in"], ctx, None, None)
                 if world == 1:
                     self.optimizer.step(tables=ctx.radam_tables, tables_dev=ctx.radam_dev)
             if world > 1:
                 g["pool"] = g["fwd_bwd"].pool()
                 g["opt"] = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g["opt"], pool=g["pool"]):
+                with torch.cuda.graph(g["opt"], pool=g["pool"], capture_error_mode="thread_local"):
                     self.optimizer.step(tables=ctx.radam_tables, tables_dev=ctx.radam_dev)
             self._graph = g
             # the capture itself executed nothing: fall through to the first replay with this step's parameters

@@ -109,6 +109,23 @@ int hpcs_vn_bwd_apply(const float* PD, const float* gout, const float* mean, con
                       const float* gamma, const float* beta, const double* red, int training, int B, int Cout,
                       int Cd, int64_t L, int pool_k, float slope, int flags, float* GPD, float* ggamma, float* gbeta,
                       hpcs_stream_t stream);
+/* The same four passes for a layer with TWO input channels (conv1: the coordinate edge feature, vn_dgcnn_partseg.py:65-66):
+ * E [B,2,3,L] is the layer's INPUT and W2 [Cout+Cd rows of pitch ldw >= 2] its stacked weight [W_feat; W_dir]; the
+ * pre-activations PD[b,ch,a,l] = fma(W2[ch][1], E[b,1,a,l], W2[ch][0] * E[b,0,a,l]) -- the k-ordered fma chain hpcs_gemm_tn
+ * evaluates, bit for bit -- are formed on the fly, so the 42-channel PD of a 2-channel input (330 MB at B=32, N=1024,
+ * k=20, touched five times per step) never exists in HBM. */
+int hpcs_vn_norm_stats_k2(const float* E, const float* W2, int ldw, int B, int Cout, int Ctot, int64_t L, double* sums,
+                          int sums_zeroed, hpcs_stream_t stream);
+int hpcs_vn_apply_fwd_k2(const float* E, const float* W2, int ldw, const float* mean, const float* rstd,
+                         const float* gamma, const float* beta, int B, int Cout, int Cd, int64_t L, int pool_k,
+                         float slope, int flags, float* out, hpcs_stream_t stream);
+int hpcs_vn_bwd_reduce_k2(const float* E, const float* W2, int ldw, const float* gout, const float* mean,
+                          const float* rstd, const float* gamma, const float* beta, int B, int Cout, int Cd, int64_t L,
+                          int pool_k, float slope, int flags, double* red, int red_zeroed, hpcs_stream_t stream);
+int hpcs_vn_bwd_apply_k2(const float* E, const float* W2, int ldw, const float* gout, const float* mean,
+                         const float* rstd, const float* gamma, const float* beta, const double* red, int training, int B,
+                         int Cout, int Cd, int64_t L, int pool_k, float slope, int flags, float* GPD, float* ggamma,
+                         float* gbeta, hpcs_stream_t stream);
 /* Fused backward of a BN + VN-LeakyReLU layer with Cd == Cout <= 24 and Cin <= 48 (the EdgeConv layers): the point-wise
  * backward (= hpcs_vn_bwd_apply), the data gradient gX [B,Cin,3,L] = W^T GPD and the weight gradient
  * dW [2*Cout, Cin] (row pitch lddw; added to when dw_accumulate != 0) = sum GPD X^T in ONE pass: GPD stays in LDS.
