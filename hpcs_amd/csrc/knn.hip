@@ -261,9 +261,13 @@ __device__ __forceinline__ unsigned long long knn_key(float s, int j) {
         (b) = sw_ ? x_ : y_;                                           \
     }
 
+// k > KK (k = 33..40 on the 32-wide lists): a query's k nearest are merged from 8 sub-lists of 32, which is exact unless one
+// sub-list would have contributed MORE than its 32 entries -- then (and only then) the merge exhausts that sub-list, the
+// workgroup raises its tile's flag and the queued kernel below recomputes the tile exactly (40 nearest with 33+ of them in
+// one of 8 interleaved candidate subsets: never observed, but not excluded, so it is detected rather than assumed).
 template <int KSTEPS, int KK>
 __global__ __launch_bounds__(MW * 64) void knn_mfma_sort_kernel(const float* __restrict__ x, const float* __restrict__ sq, int D,
-                                                                int N, int k, int64_t* __restrict__ idx) {
+                                                                int N, int k, int64_t* __restrict__ idx, int* __restrict__ redo) {
     static_assert(KK <= 32, "the merge network is 32 wide");
     __shared__ unsigned long long lkey[MQ][2 * MW][KK];
     const int tiles_q = (N + MQ - 1) / MQ;
@@ -367,6 +371,12 @@ __global__ __launch_bounds__(MW * 64) void knn_mfma_sort_kernel(const float* __r
             for (int u = 0; u < 2 * MW; ++u) head[u] += (u == bu) ? 1 : 0;
             o[m] = (int64_t)(0xFFFFFFFFu - (unsigned)(bestk & 0xFFFFFFFFull));
         }
+        if (redo && k > KK) {
+            bool exhausted = false;
+#pragma unroll
+            for (int u = 0; u < 2 * MW; ++u) exhausted = exhausted || head[u] >= KK;
+            if (exhausted) redo[blockIdx.x] = 1;
+        }
     }
 }
 
@@ -385,7 +395,9 @@ constexpr int QCAP = 24;       // queue slots per lane: a tile appends at most 1
 // only adds work (measured 337 vs 157 us for the queue-less 4-wave kernel at B=32, N=1024, k=20).
 template <int KSTEPS, int KK, int NW>
 __global__ __launch_bounds__(NW * 64) void knn_mfma_queue_kernel(const float* __restrict__ x, const float* __restrict__ sq, int D,
-                                                                 int N, int k, int64_t* __restrict__ idx) {
+                                                                 int N, int k, int64_t* __restrict__ idx,
+                                                                 const int* __restrict__ only_flagged) {
+    if (only_flagged && !only_flagged[blockIdx.x]) return;        // repair pass behind the sorting-network kernel (k > 32)
     __shared__ float qv_[NW][QCAP][64];
     __shared__ int qi_[NW][QCAP][64];
     __shared__ float lval[MQ][2 * NW][KK];
@@ -505,27 +517,35 @@ __global__ __launch_bounds__(NW * 64) void knn_mfma_queue_kernel(const float* __
 }
 
 template <int KSTEPS>
-int launch_knn_mfma(const float* x, const float* sq, int B, int D, int N, int k, int64_t* idx, hipStream_t st) {
+int launch_knn_mfma(const float* x, const float* sq, int B, int D, int N, int k, int64_t* idx, int* redo, hipStream_t st) {
     const int tiles_q = (N + MQ - 1) / MQ;
     const dim3 grid((unsigned)(B * tiles_q));
     // Measured (MI355X, us): k = 20, N = 1024     B=32 D=3   B=32 D=63   B=512 D=3   B=512 D=63
     //   sorting-network kernel (4 waves)            96        168         1118        2324
     //   per-score insertion kernel (4 waves)       156        243         1729        3500
     //   queued single-wave kernel                  167        229         1508        2274
-    // and for N = 2048, k = 40 (lists longer than the 32-wide merge network): queued 390-500 us, insertion 817-894 us.
-    // So: k <= 32 -> sorting network, k > 32 -> queued kernel.
+    // and for N = 2048, k = 40 (lists longer than the 32-wide merge network): queued 390-500 us, insertion 817-894 us;
+    // r02: sorting network on 32-wide lists + flagged exact repair (see knn_mfma_sort_kernel): measured below.
+    // So: k <= 32 -> sorting network; 32 < k <= 40 -> sorting network with 32-wide lists + repair pass of the queued kernel.
     const char* e = getenv("HPCS_KNN_KERNEL");     // tiled|queue overrides the choice (A/B tests; read on every call)
     const int force = !e ? 0 : (e[0] == 't' ? 1 : (e[0] == 'i' ? 3 : 2));      // tiled (sorting network) | insert | queue
     const bool tiled = force == 1 || force == 3 || (force == 0 && k <= 32);
+    if (k > 32 && redo && (force == 0 || force == 1)) {
+        if (hipMemsetAsync(redo, 0, sizeof(int) * grid.x, st) != hipSuccess) return HPCS_ERR_HIP;
+        hipLaunchKernelGGL((knn_mfma_sort_kernel<KSTEPS, 32>), grid, dim3(MW * 64), 0, st, x, sq, D, N, k, idx, redo);
+        hipLaunchKernelGGL((knn_mfma_queue_kernel<KSTEPS, 40, 1>), grid, dim3(64), 0, st, x, sq, D, N, k, idx, (const int*)redo);
+        return HPCS_OK;
+    }
 #define HPCS_KNNM_CASE(KK)                                                                                   \
     if (k <= KK) {                                                                                            \
         if (tiled && KK <= 32 && force != 3)                                                                  \
             hipLaunchKernelGGL((knn_mfma_sort_kernel<KSTEPS, (KK <= 32 ? KK : 32)>), grid, dim3(MW * 64), 0, st, x, sq, D, N, k, \
-                               idx);                                                                          \
+                               idx, (int*)nullptr);                                                           \
         else if (tiled)                                                                                       \
             hipLaunchKernelGGL((knn_mfma_kernel<KSTEPS, KK>), grid, dim3(MW * 64), 0, st, x, sq, D, N, k, idx); \
         else                                                                                                  \
-            hipLaunchKernelGGL((knn_mfma_queue_kernel<KSTEPS, KK, 1>), grid, dim3(64), 0, st, x, sq, D, N, k, idx); \
+            hipLaunchKernelGGL((knn_mfma_queue_kernel<KSTEPS, KK, 1>), grid, dim3(64), 0, st, x, sq, D, N, k, idx, \
+                               (const int*)nullptr);                                                          \
         return HPCS_OK;                                                                                       \
     }
     HPCS_KNNM_CASE(4)
@@ -569,7 +589,8 @@ int launch_knn(const float* x, int B, int D, int N, int k, int64_t* idx, hipStre
 
 extern "C" size_t hpcs_knn_workspace(int B, int N) {
     if (B <= 0 || N <= 0) return 64;
-    return (size_t)B * N * sizeof(float);
+    // |x|^2 per point + one repair flag per 32-query tile (k > 32)
+    return (size_t)B * N * sizeof(float) + (size_t)B * ((N + MQ - 1) / MQ) * sizeof(int);
 }
 
 extern "C" int hpcs_knn(const float* x, int B, int D, int N, int k, int64_t* idx, void* ws, size_t ws_bytes,
@@ -586,7 +607,8 @@ extern "C" int hpcs_knn(const float* x, int B, int D, int N, int k, int64_t* idx
         const int64_t total = (int64_t)B * N;
         hipLaunchKernelGGL(knn_sumsq_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, D, N, total, sq);
         HPCS_CHECK_LAUNCH();
-        rc = D == 3 ? launch_knn_mfma<2>(x, sq, B, D, N, k, idx, st) : launch_knn_mfma<32>(x, sq, B, D, N, k, idx, st);
+        int* redo = reinterpret_cast<int*>(sq + (size_t)B * N);
+        rc = D == 3 ? launch_knn_mfma<2>(x, sq, B, D, N, k, idx, redo, st) : launch_knn_mfma<32>(x, sq, B, D, N, k, idx, redo, st);
     } else if (D == 3) {
         rc = launch_knn<3, 256>(x, B, D, N, k, idx, st);
     } else if (D == 63) {

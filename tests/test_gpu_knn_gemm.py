@@ -46,6 +46,24 @@ def test_knn_both_mfma_kernels_bit_exact(kernel, monkeypatch):
     assert torch.equal(hip_knn(x, 8), OE.knn_exact(x, 8))
 
 
+@pytest.mark.parametrize("D", [3, 63])
+def test_knn_k40_repair_pass_when_one_sublist_holds_all_neighbours(D):
+    """k in 33..40 runs the sorting-network kernel on 32-wide per-lane lists and merges a query's k nearest from 8
+    sub-lists (4 waves x 2 lane halves, interleaved candidate tiles); that is exact unless ONE sub-list would have to supply
+    more than 32 of them -- then the merge exhausts it, the tile is flagged and the queued kernel recomputes it.  Adversarial
+    cloud: the 40 mutually nearest points all sit at candidate indices of sub-list (wave 0, half 0), i.e. tile % 4 == 0 and
+    (position in tile / 4) % 2 == 0, so the repair pass MUST run for their tiles; every query is still checked bit-exactly."""
+    N, k = 2048, 40
+    x = det_cloud(1, N, 71) if D == 3 else det_normalish((1, D, N), 72)
+    special = [128 * a + p for a in range(3) for p in (0, 1, 2, 3, 8, 9, 10, 11, 16, 17, 18, 19, 24, 25, 26, 27)][:40]
+    tight = det_uniform((D, 40), 73) * 1e-3               # a tight cluster far from the rest of the cloud
+    x[0][:, special] = tight + 5.0
+    want = OE.knn_exact(x, k)
+    got = hip_knn(x, k)
+    assert torch.equal(got, want)
+    assert set(got[0, special[0]].tolist()) == set(special)          # the cluster's neighbours are the cluster
+
+
 def test_knn_duplicates_and_golden(golden):
     x = det_cloud(2, 128, 13, dup_every=5)
     assert torch.equal(hip_knn(x, 8), OE.knn_exact(x, 8))
