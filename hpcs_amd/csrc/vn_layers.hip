@@ -694,6 +694,134 @@ __global__ __launch_bounds__(TPB) void vn_bwd_reduce_vec_kernel(const float* __r
     }
 }
 
+// ---- two-input-channel layers, all output channels per thread (conv1: Cout = Cd = COUT = 21) ---------------------------
+// A thread owns 4 consecutive positions: it loads the edge feature once (six 16-byte loads) and walks the COUT channels
+// with the weights in scalar registers, so E is read ONCE per pass instead of once per channel (the per-channel K2 kernels
+// re-read it 21 times through L2: 61 us for the statistics against 42 us for reading a materialised PD).
+template <int COUT>
+__device__ __forceinline__ void k2_block_reduce(float (&s1)[COUT], float (&s2)[COUT], double* __restrict__ out, int Cout) {
+    __shared__ float part[2 * COUT][TPB / 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) {
+        const float a = hpcs_wave_sum(s1[c]), b = hpcs_wave_sum(s2[c]);
+        if (lane == 0) { part[c][wv] = a; part[COUT + c][wv] = b; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * COUT) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < TPB / 64; ++w) t += (double)part[threadIdx.x][w];
+        const int c = threadIdx.x < COUT ? threadIdx.x : threadIdx.x - COUT;
+        atomicAdd(out + (threadIdx.x < COUT ? c : Cout + c), t);
+    }
+}
+
+template <int COUT>
+__global__ __launch_bounds__(TPB) void vn_norm_stats_k2all_kernel(const float* __restrict__ E, const float* __restrict__ w2, int ldw,
+                                                                 int64_t L, double* __restrict__ sums) {
+    const int b = blockIdx.y;
+    const int64_t l = ((int64_t)blockIdx.x * TPB + threadIdx.x) * 4;
+    float s1[COUT], s2[COUT];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) s1[c] = s2[c] = 0.f;
+    if (l < L) {
+        float4 e0[3], e1[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            e0[a] = *reinterpret_cast<const float4*>(E + (((int64_t)b * 2 + 0) * 3 + a) * L + l);
+            e1[a] = *reinterpret_cast<const float4*>(E + (((int64_t)b * 2 + 1) * 3 + a) * L + l);
+        }
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) {
+            const float w0 = w2[(int64_t)c * ldw], w1 = w2[(int64_t)c * ldw + 1];
+            float p[3][4];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                p[a][0] = __fmaf_rn(w1, e1[a].x, __fmul_rn(w0, e0[a].x));
+                p[a][1] = __fmaf_rn(w1, e1[a].y, __fmul_rn(w0, e0[a].y));
+                p[a][2] = __fmaf_rn(w1, e1[a].z, __fmul_rn(w0, e0[a].z));
+                p[a][3] = __fmaf_rn(w1, e1[a].w, __fmul_rn(w0, e0[a].w));
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float n = sqrtf(p[0][q] * p[0][q] + p[1][q] * p[1][q] + p[2][q] * p[2][q]) + VN_EPS;
+                s1[c] += n;
+                s2[c] += n * n;
+            }
+        }
+    }
+    k2_block_reduce<COUT>(s1, s2, sums, COUT);
+}
+
+// The backward reduction walks the channels in a ROLLED loop (its body -- forward point, leaky-ReLU and norm backward of four
+// positions -- unrolled 21 times spilled: 370 us) with the next channel's gradient plane prefetched under the arithmetic of the
+// current one (without the prefetch the loop is 21 serial HBM round trips: 290 us at N=2048); a channel's two sums are reduced
+// across the wave at once, so the block keeps 2*COUT*4 floats of LDS.
+template <int COUT>
+__global__ __launch_bounds__(TPB) void vn_bwd_reduce_k2all_kernel(const float* __restrict__ E, const float* __restrict__ w2, int ldw,
+                                                                 const float* __restrict__ gout, const float* __restrict__ mean,
+                                                                 const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, int64_t L, float slope, int flags,
+                                                                 double* __restrict__ red_out) {
+    __shared__ float part[2 * COUT][TPB / 64];
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t l0 = ((int64_t)blockIdx.x * TPB + tid) * 4;
+    const bool live = l0 < L;
+    const int64_t l = live ? l0 : 0;                       // dead threads read position 0 and contribute nothing
+    float e0v[3][4], e1v[3][4];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float4 u = *reinterpret_cast<const float4*>(E + (((int64_t)b * 2 + 0) * 3 + a) * L + l);
+        const float4 v = *reinterpret_cast<const float4*>(E + (((int64_t)b * 2 + 1) * 3 + a) * L + l);
+        e0v[a][0] = u.x; e0v[a][1] = u.y; e0v[a][2] = u.z; e0v[a][3] = u.w;
+        e1v[a][0] = v.x; e1v[a][1] = v.y; e1v[a][2] = v.z; e1v[a][3] = v.w;
+    }
+    const float* gp = gout + ((int64_t)b * COUT * 3) * L + l;
+    float4 gn[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) gn[a] = *reinterpret_cast<const float4*>(gp + a * L);
+#pragma unroll 1
+    for (int c = 0; c < COUT; ++c) {
+        float gv[3][4];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { gv[a][0] = gn[a].x; gv[a][1] = gn[a].y; gv[a][2] = gn[a].z; gv[a][3] = gn[a].w; }
+        const int cn = c + 1 < COUT ? c + 1 : c;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) gn[a] = *reinterpret_cast<const float4*>(gp + ((int64_t)cn * 3 + a) * L);
+        const float wp0 = w2[(int64_t)c * ldw], wp1 = w2[(int64_t)c * ldw + 1];
+        const float wd0 = w2[(int64_t)(COUT + c) * ldw], wd1 = w2[(int64_t)(COUT + c) * ldw + 1];
+        const float mu = mean[c], rs = rstd[c], ga = gamma[c], be = beta[c];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            VnPoint sp;
+            float g[3], gq[3], gd[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                sp.p[a] = __fmaf_rn(wp1, e1v[a][q], __fmul_rn(wp0, e0v[a][q]));
+                sp.d[a] = __fmaf_rn(wd1, e1v[a][q], __fmul_rn(wd0, e0v[a][q]));
+                g[a] = gv[a][q];
+            }
+            vn_forward_point(sp, mu, rs, ga, be, flags);
+            vn_lrelu_bwd_point(sp, g, slope, flags, gq, gd);
+            const float gnb = (gq[0] * sp.p[0] + gq[1] * sp.p[1] + gq[2] * sp.p[2]) / sp.n;
+            s1 += gnb;
+            s2 += gnb * sp.xhat;
+        }
+        s1 = hpcs_wave_sum(live ? s1 : 0.f);
+        s2 = hpcs_wave_sum(live ? s2 : 0.f);
+        if (lane == 0) { part[c][wv] = s1; part[COUT + c][wv] = s2; }
+    }
+    __syncthreads();
+    if (tid < 2 * COUT) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < TPB / 64; ++w) t += (double)part[tid][w];
+        atomicAdd(red_out + tid, t);                       // [0,COUT): sum gnb, [COUT,2COUT): sum gnb*xhat
+    }
+}
+
 template <bool SHARED>
 __global__ void vn_bwd_apply_kernel(PdRef pd, const float* __restrict__ gout,
                                     const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -1926,6 +2054,9 @@ static int vn_norm_stats_impl(PdRef pd, int B, int Cout, double* sums, int zeroe
     if (vec_ok && pd.w2 == nullptr)
         hipLaunchKernelGGL(vn_norm_stats_vec_kernel<false>, dim3(hpcs_cdiv(pd.L, TPB * 4 * VEC_ITEMS), Cout, B), dim3(TPB), 0, st,
                            pd.base, pd.Ctot, pd.L, Cout, sums, (const float*)nullptr, 0);
+    else if (vec_ok && Cout == 21 && pd.Ctot == 42)
+        hipLaunchKernelGGL(vn_norm_stats_k2all_kernel<21>, dim3(hpcs_cdiv(pd.L, TPB * 4), B), dim3(TPB), 0, st, pd.base, pd.w2,
+                           pd.ldw, pd.L, sums);
     else if (vec_ok)
         hipLaunchKernelGGL(vn_norm_stats_vec_kernel<true>, dim3(hpcs_cdiv(pd.L, TPB * 4 * VEC_ITEMS), Cout, B), dim3(TPB), 0, st,
                            pd.base, pd.Ctot, pd.L, Cout, sums, pd.w2, pd.ldw);
@@ -2003,6 +2134,9 @@ static int vn_bwd_reduce_impl(PdRef pd, const float* gout, const float* mean, co
     if (vec && pd.w2 == nullptr)
         hipLaunchKernelGGL(vn_bwd_reduce_vec_kernel<false>, dim3(hpcs_cdiv(pd.L, TPB * 4 * VEC_ITEMS), Cout, B), dim3(TPB), 0, st,
                            pd.base, gout, mean, rstd, gamma, beta, Cout, Cd, pd.L, pool_k, slope, flags, red, (const float*)nullptr, 0);
+    else if (vec && pool_k == 0 && Cout == 21 && Cd == 21 && flags == (HPCS_VN_BN | HPCS_VN_LRELU))
+        hipLaunchKernelGGL(vn_bwd_reduce_k2all_kernel<21>, dim3(hpcs_cdiv(pd.L, TPB * 4), B), dim3(TPB), 0, st, pd.base, pd.w2,
+                           pd.ldw, gout, mean, rstd, gamma, beta, pd.L, slope, flags, red);
     else if (vec)
         hipLaunchKernelGGL(vn_bwd_reduce_vec_kernel<true>, dim3(hpcs_cdiv(pd.L, TPB * 4 * VEC_ITEMS), Cout, B), dim3(TPB), 0, st,
                            pd.base, gout, mean, rstd, gamma, beta, Cout, Cd, pd.L, pool_k, slope, flags, red, pd.w2, pd.ldw);

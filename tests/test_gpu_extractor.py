@@ -426,7 +426,9 @@ def test_edge_grad_reduce_transposed_graph(B, Ctot, N, k, hub):
                                         (21, True, 2048, 40)])
 def test_graph_layer_point_level_backward(C, pool, N, k):
     """forward_graph: forward BIT-identical to the layer on the materialised graph feature; the point-level backward
-    (graph reduction first, then k-times smaller GEMMs) gives the same gradients up to fp32 reassociation."""
+    (graph reduction first, then k-times smaller GEMMs) gives the same gradients up to fp32 reassociation.  C=1 is conv1's
+    two-channel case: its pre-activations are formed on the fly with the GEMM's own fma chain (bit-identical), but its
+    batch statistics are summed all-channels-per-thread, i.e. in another order -> the forward agrees to an ulp, not a bit."""
     from hpcs_amd.nn.dgcnn.utils.vn_layers import VNLinearLeakyReLU
     from hpcs_amd.nn.dgcnn.utils.vn_dgcnn_util import get_graph_feature
     B = 3
@@ -445,8 +447,12 @@ def test_graph_layer_point_level_backward(C, pool, N, k):
         (y * w).sum().backward()
         res.append((y.detach(), fg.grad, m.map_to_feat.weight.grad, m.map_to_dir.weight.grad, m.batchnorm.bn.weight.grad,
                     m.batchnorm.bn.bias.grad, m.batchnorm.bn.running_var.clone()))
-    assert torch.equal(res[0][0], res[1][0])
-    assert torch.equal(res[0][6], res[1][6])
+    if C == 1:
+        assert float((res[0][0] - res[1][0]).abs().max()) <= 1e-6 * float(res[1][0].abs().max())
+        assert torch.allclose(res[0][6], res[1][6], rtol=1e-6, atol=0)
+    else:
+        assert torch.equal(res[0][0], res[1][0])
+        assert torch.equal(res[0][6], res[1][6])
     for a, b in zip(res[0][1:6], res[1][1:6]):
         relclose(a, b, 5e-5)
 
