@@ -17,6 +17,19 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // register image of a 16-byte load (a native vector: always SSA)
+
+// -DHPCS_TN_STAMPS (scratch builds only): every workgroup of gemm_tn_kernel records shader-clock stamps at its phase
+// boundaries (100 MHz wall clock: start | first tile staged | main loop done | epilogue done) + its XCC/CU id into g_tn_stamps[5 * logical].
+#ifdef HPCS_TN_STAMPS
+__device__ long long* g_tn_stamps = nullptr;
+#define TN_STAMP(i)                                                                    \
+    do {                                                                               \
+        if (g_tn_stamps && threadIdx.x == 0) g_tn_stamps[5 * (size_t)blockIdx.x + (i)] = (long long)wall_clock64(); \
+    } while (0)
+#else
+#define TN_STAMP(i) do { } while (0)
+#endif
 
 __device__ __forceinline__ float4 ld4_guard(const float* __restrict__ rowp, int col, int ncols, bool rowok,
                                             bool vec) {
@@ -30,8 +43,12 @@ __device__ __forceinline__ float4 ld4_guard(const float* __restrict__ rowp, int 
     return v;
 }
 
-template <int BM, int BN, int BK, int WM, int WN>
-__global__ __launch_bounds__(WM* WN * 64, 4) void gemm_tn_kernel(
+// FAST: both operands are 16-byte loadable everywhere (lda, ldb, Nc multiples of 4, aligned bases, K >= BK): the loader is
+// straight-line code -- clamped addresses instead of guards (a clamped column only feeds output rows / columns that are never
+// stored; rows beyond K are zeroed in the last K step only) -- so that the compiler can count the loads in flight
+// (`vmcnt(n)`, not the `vmcnt(0)` it falls back to behind guard branches).
+template <int BM, int BN, int BK, int WM, int WN, int PF = 1, int OCC = 4, bool FAST = false>
+__global__ __launch_bounds__(WM* WN * 64, OCC) void gemm_tn_kernel(
     const float* __restrict__ At, int lda, const float* __restrict__ Bm, int ldb, int64_t sBo, int64_t sBi,
     float* __restrict__ C, int ldc, int64_t sCo, int64_t sCi, int M, int Nc, int K, int n_inner,
     const float* __restrict__ rowbias, int accumulate, int tilesM, int tilesN, unsigned total, int vecA,
@@ -45,6 +62,7 @@ __global__ __launch_bounds__(WM* WN * 64, 4) void gemm_tn_kernel(
     float (*As)[BK][BM] = reinterpret_cast<float (*)[BK][BM]>(lds_raw);
     float (*Bs)[BK][BN] = reinterpret_cast<float (*)[BK][BN]>(lds_raw + 2 * BK * BM);
 
+    TN_STAMP(0);
     const unsigned logical = hpcs_xcd_remap(blockIdx.x, total);
     const int rowTile = logical % tilesM;
     const unsigned t1 = logical / tilesM;
@@ -66,36 +84,74 @@ __global__ __launch_bounds__(WM* WN * 64, 4) void gemm_tn_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 ra[A_LD], rb[B_LD];
-    auto gload = [&](int k0) {
+    // two register sets: set 0 is the one-step prefetch; PF == 2 uses set 1 for the second step in flight
+    f32x4 rA[PF][A_LD], rB[PF][B_LD];
+    // FAST loader state: per-thread column offsets are fixed, only the row advances
+    int colA[A_LD], colB[B_LD], rowA[A_LD], rowB[B_LD];
+    if constexpr (FAST) {
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            const int f = tid + i * NT;
+            rowA[i] = f / (BM / 4);
+            colA[i] = min(m0 + (f % (BM / 4)) * 4, lda - 4);
+        }
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) {
+            const int f = tid + i * NT;
+            rowB[i] = f / (BN / 4);
+            colB[i] = min(n0 + (f % (BN / 4)) * 4, Nc - 4);
+        }
+    }
+    auto gload = [&](int k0, auto set) {
+        constexpr int S = decltype(set)::value;
+        if constexpr (FAST) {
+#pragma unroll
+            for (int i = 0; i < A_LD; ++i)
+                rA[S][i] = *reinterpret_cast<const f32x4*>(At + (int64_t)min(k0 + rowA[i], K - 1) * lda + colA[i]);
+#pragma unroll
+            for (int i = 0; i < B_LD; ++i)
+                rB[S][i] = *reinterpret_cast<const f32x4*>(Bp + (int64_t)min(k0 + rowB[i], K - 1) * ldb + colB[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_LD; ++i) {
+                const int f = tid + i * NT, row = f / (BM / 4), c4 = (f % (BM / 4)) * 4;
+                const float4 q = ld4_guard(At + (int64_t)(k0 + row) * lda, m0 + c4, M, k0 + row < K, vecA);
+                rA[S][i] = f32x4{q.x, q.y, q.z, q.w};
+            }
+#pragma unroll
+            for (int i = 0; i < B_LD; ++i) {
+                const int f = tid + i * NT, row = f / (BN / 4), c4 = (f % (BN / 4)) * 4;
+                const float4 q = ld4_guard(Bp + (int64_t)(k0 + row) * ldb, n0 + c4, Nc, k0 + row < K, vecB);
+                rB[S][i] = f32x4{q.x, q.y, q.z, q.w};
+            }
+        }
+    };
+    auto lstore = [&](int buf, int k0, auto set) {
+        constexpr int S = decltype(set)::value;
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
             const int f = tid + i * NT, row = f / (BM / 4), c4 = (f % (BM / 4)) * 4;
-            ra[i] = ld4_guard(At + (int64_t)(k0 + row) * lda, m0 + c4, M, k0 + row < K, vecA);
+            f32x4 v = rA[S][i];
+            // FAST: rows beyond K (last K step) are zeroed in A -- B's are finite copies of row K-1, their products vanish
+            if constexpr (FAST) {
+                if (k0 + row >= K) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            *reinterpret_cast<f32x4*>(&As[buf][row][c4]) = v;
         }
 #pragma unroll
         for (int i = 0; i < B_LD; ++i) {
             const int f = tid + i * NT, row = f / (BN / 4), c4 = (f % (BN / 4)) * 4;
-            rb[i] = ld4_guard(Bp + (int64_t)(k0 + row) * ldb, n0 + c4, Nc, k0 + row < K, vecB);
+            *reinterpret_cast<f32x4*>(&Bs[buf][row][c4]) = rB[S][i];
         }
     };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < A_LD; ++i) {
-            const int f = tid + i * NT, row = f / (BM / 4), c4 = (f % (BM / 4)) * 4;
-            *reinterpret_cast<float4*>(&As[buf][row][c4]) = ra[i];
-        }
-#pragma unroll
-        for (int i = 0; i < B_LD; ++i) {
-            const int f = tid + i * NT, row = f / (BN / 4), c4 = (f % (BN / 4)) * 4;
-            *reinterpret_cast<float4*>(&Bs[buf][row][c4]) = rb[i];
-        }
-    };
+    constexpr std::integral_constant<int, 0> S0{};
+    constexpr std::integral_constant<int, PF - 1> S1{};
 
     const int nk = (K + BK - 1) / BK;
-    gload(0);
-    lstore(0);
+    gload(0, S0);
+    lstore(0, 0, S0);
     __syncthreads();
+    TN_STAMP(1);
     const int lr = lane & 31, lk = lane >> 5;
     // 32x32 sub-tiles that lie entirely in the padding of an edge tile (M = 341 / 682 leave 32-64 dead rows in the last
     // 128-row tile) issue no MFMA: the matrix pipe of that SIMD goes to the other resident workgroup instead
@@ -124,15 +180,38 @@ __global__ __launch_bounds__(WM* WN * 64, 4) void gemm_tn_kernel(
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     };
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) gload((kt + 1) * BK);
-        if (all_live) mma(buf, std::true_type{});
-        else mma(buf, std::false_type{});
-        if (kt + 1 < nk) lstore(buf ^ 1);
-        __syncthreads();
+    if constexpr (PF == 1) {
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) gload((kt + 1) * BK, S0);
+            if (all_live) mma(buf, std::true_type{});
+            else mma(buf, std::false_type{});
+            if (kt + 1 < nk) lstore(buf ^ 1, (kt + 1) * BK, S0);
+            __syncthreads();
+        }
+    } else {
+        // Two K steps of prefetch distance: while the MFMAs of step kt run from LDS, the registers of step kt+1 (requested one
+        // iteration ago) are stored to the other LDS buffer and step kt+2 is requested into the second register set -- a
+        // global load has a whole iteration (not just one MFMA group) to arrive before `vmcnt` waits for it.
+        if (nk > 1) gload(BK, S0);                                // step 1 -> set 0
+        for (int kt = 0; kt < nk; kt += 2) {
+            // even step: LDS buffer 0 holds kt, set 0 holds kt+1, request kt+2 into set 1
+            if (kt + 2 < nk) gload((kt + 2) * BK, S1);
+            if (all_live) mma(0, std::true_type{});
+            else mma(0, std::false_type{});
+            if (kt + 1 < nk) lstore(1, (kt + 1) * BK, S0);
+            __syncthreads();
+            if (kt + 1 >= nk) break;
+            // odd step: LDS buffer 1 holds kt+1, set 1 holds kt+2, request kt+3 into set 0
+            if (kt + 3 < nk) gload((kt + 3) * BK, S0);
+            if (all_live) mma(1, std::true_type{});
+            else mma(1, std::false_type{});
+            if (kt + 2 < nk) lstore(0, (kt + 2) * BK, S1);
+            __syncthreads();
+        }
     }
 
+    TN_STAMP(2);
     const float* bias = rowbias ? rowbias + (int64_t)batch * M : nullptr;
     if (vecC) {
         // Epilogue through a wave-private LDS patch: the MFMA result holds 4-row x 1-column slivers per lane, i.e. one
@@ -175,6 +254,7 @@ __global__ __launch_bounds__(WM* WN * 64, 4) void gemm_tn_kernel(
                 }
                 __builtin_amdgcn_s_waitcnt(0xC07F);              // the reads are done before the next tile overwrites
             }
+        TN_STAMP(3);
         return;
     }
 #pragma unroll
@@ -609,6 +689,12 @@ inline bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
 
 }  // namespace
 
+#ifdef HPCS_TN_STAMPS
+extern "C" int hpcs_debug_tn_stamps(long long* p) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_tn_stamps), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 extern "C" int hpcs_gemm_tn(const float* At, int lda, const float* Bm, int ldb, int64_t strideB_o, int64_t strideB_i,
                             float* C, int ldc, int64_t strideC_o, int64_t strideC_i, int M, int Nc, int K, int n_outer,
                             int n_inner, const float* rowbias, int accumulate, hpcs_stream_t stream) {
@@ -635,22 +721,37 @@ extern "C" int hpcs_gemm_tn(const float* At, int lda, const float* Bm, int ldb, 
             return HPCS_OK;
         }
     }
+    // straight-line loader: every 16-byte load of both operands is in bounds after clamping (see gemm_tn_kernel)
+    const bool fast = vecA && vecB && Nc % 4 == 0 && Nc >= 4 && lda >= 4;
     if (M > 64) {
         constexpr int BM = 128, BN = 128, BK = 16;
         const int tm = hpcs_cdiv(M, BM), tn = hpcs_cdiv(Nc, BN);
         const long total = (long)tm * tn * nb;
         if (total > 0x7fffffffL) return HPCS_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, BK, 2, 2>), dim3((unsigned)total), dim3(256), 0, st, At, lda, Bm,
-                           ldb, strideB_o, strideB_i, C, ldc, strideC_o, strideC_i, M, Nc, K, n_inner, rowbias,
-                           accumulate, tm, tn, (unsigned)total, vecA, vecB, vecC);
+        // HPCS_GEMM_TN_VAR (A/B switch): 0 = default (straight-line loader where the operands allow it), 1 = guarded loader
+        static int var = -1;
+        if (var < 0) { const char* e = getenv("HPCS_GEMM_TN_VAR"); var = e ? atoi(e) : 0; }
+        if (fast && var != 1)
+            hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, BK, 2, 2, 1, 4, true>), dim3((unsigned)total), dim3(256), 0, st, At, lda, Bm,
+                               ldb, strideB_o, strideB_i, C, ldc, strideC_o, strideC_i, M, Nc, K, n_inner, rowbias,
+                               accumulate, tm, tn, (unsigned)total, vecA, vecB, vecC);
+        else
+            hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, BK, 2, 2, 1, 4, false>), dim3((unsigned)total), dim3(256), 0, st, At, lda, Bm,
+                               ldb, strideB_o, strideB_i, C, ldc, strideC_o, strideC_i, M, Nc, K, n_inner, rowbias,
+                               accumulate, tm, tn, (unsigned)total, vecA, vecB, vecC);
     } else {
         constexpr int BM = 64, BN = 128, BK = 16;
         const int tm = hpcs_cdiv(M, BM), tn = hpcs_cdiv(Nc, BN);
         const long total = (long)tm * tn * nb;
         if (total > 0x7fffffffL) return HPCS_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, BK, 1, 4>), dim3((unsigned)total), dim3(256), 0, st, At, lda, Bm,
-                           ldb, strideB_o, strideB_i, C, ldc, strideC_o, strideC_i, M, Nc, K, n_inner, rowbias,
-                           accumulate, tm, tn, (unsigned)total, vecA, vecB, vecC);
+        if (fast)
+            hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, BK, 1, 4, 1, 4, true>), dim3((unsigned)total), dim3(256), 0, st, At, lda, Bm,
+                               ldb, strideB_o, strideB_i, C, ldc, strideC_o, strideC_i, M, Nc, K, n_inner, rowbias,
+                               accumulate, tm, tn, (unsigned)total, vecA, vecB, vecC);
+        else
+            hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, BK, 1, 4, 1, 4, false>), dim3((unsigned)total), dim3(256), 0, st, At, lda, Bm,
+                               ldb, strideB_o, strideB_i, C, ldc, strideC_o, strideC_i, M, Nc, K, n_inner, rowbias,
+                               accumulate, tm, tn, (unsigned)total, vecA, vecB, vecC);
     }
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;

@@ -129,6 +129,29 @@ def test_vn_linear_leaky_relu_dim4_shared(golden):
     close(m(x4.to(dev)), golden["vnllr4s_eval_out"], rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("B,Cin,Cout,L", [(4, 42, 341, 1024), (2, 42, 341, 2048), (3, 6, 10, 50), (2, 5, 3, 8)])
+def test_shared_direction_layer_vs_fp64_oracle(B, Cin, Cout, L):
+    """conv6's shape (one direction channel for 341 feature channels): forward and every gradient against the oracle in
+    fp64.  L % 4 == 0 takes the four-positions-per-thread backward kernel, L = 50 the scalar one."""
+    from hpcs_amd.nn.dgcnn.utils.vn_layers import VNLinearLeakyReLU
+    x = det_normalish((B, Cin, 3, L), 40 + L)
+    m = load(VNLinearLeakyReLU(Cin, Cout, dim=4, share_nonlinearity=True), 41)
+    m.train()
+    P = {"c." + k_: v.detach().cpu().double().requires_grad_(v.dtype.is_floating_point and "running" not in k_)
+         for k_, v in m.state_dict().items()}
+    xg = x.to(dev).requires_grad_(True)
+    y = m(xg)
+    w = det_uniform(tuple(y.shape), 42)
+    (y * w.to(dev)).sum().backward()
+    xr = x.double().requires_grad_(True)
+    yr = OE.vn_linear_leaky_relu(xr, P, "c", True)
+    (yr * w.double()).sum().backward()
+    relclose(y, yr, 2e-6)
+    relclose(xg.grad, xr.grad, 2e-5)
+    for n_, p_ in m.named_parameters():
+        relclose(p_.grad, P["c." + n_].grad, 5e-5)
+
+
 def test_fused_mean_pool_matches_unfused():
     from hpcs_amd.nn.dgcnn.utils.vn_layers import VNLinearLeakyReLU, mean_pool
     x5 = det_normalish((2, 6, 3, 16, 4), 30).to(dev)
