@@ -43,35 +43,24 @@ __device__ __forceinline__ float4 ld4_guard(const float* __restrict__ rowp, int 
     return v;
 }
 
-// FAST: both operands are 16-byte loadable everywhere (lda, ldb, Nc multiples of 4, aligned bases, K >= BK): the loader is
+// One output tile of C = At^T * B: BM x BN, WM x WN waves of (BM/WM) x (BN/WN) each, BK-deep K steps, double-buffered LDS.
+// FAST: both operands are 16-byte loadable everywhere (lda, ldb, Nc multiples of 4, aligned bases): the loader is
 // straight-line code -- clamped addresses instead of guards (a clamped column only feeds output rows / columns that are never
-// stored; rows beyond K are zeroed in the last K step only) -- so that the compiler can count the loads in flight
-// (`vmcnt(n)`, not the `vmcnt(0)` it falls back to behind guard branches).
-template <int BM, int BN, int BK, int WM, int WN, int PF = 1, int OCC = 4, bool FAST = false>
-__global__ __launch_bounds__(WM* WN * 64, OCC) void gemm_tn_kernel(
-    const float* __restrict__ At, int lda, const float* __restrict__ Bm, int ldb, int64_t sBo, int64_t sBi,
-    float* __restrict__ C, int ldc, int64_t sCo, int64_t sCi, int M, int Nc, int K, int n_inner,
-    const float* __restrict__ rowbias, int accumulate, int tilesM, int tilesN, unsigned total, int vecA,
-    int vecB, int vecC) {
+// stored; A's rows beyond K are zeroed on their way to LDS, B's are finite copies of row K-1) -- so that the compiler can
+// count the loads in flight (`vmcnt(n)`; behind guard branches it falls back to `vmcnt(0)` and a maze of exec-mask
+// branches: 509 -> 487 us on vn1's forward, 57 -> 48 us on conv6's).  Measured on top of it and NOT kept: a second K step
+// of prefetch distance (two register sets, 124 VGPRs, still four waves per SIMD): 484 vs 487 us.
+template <int BM, int BN, int BK, int WM, int WN, bool FAST>
+__device__ __forceinline__ void tn_tile(const float* __restrict__ At, int lda, const float* __restrict__ Bp, int ldb,
+                                        float* __restrict__ Cp, int ldc, int M, int Nc, int K, const float* __restrict__ bias,
+                                        int accumulate, int m0, int n0, int vecA, int vecB, int vecC, float* lds_raw) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int A_LD = BK * BM / 4 / NT, B_LD = BK * BN / 4 / NT;
-    static_assert(A_LD >= 1 && B_LD >= 1, "tile too small for the thread count");
-    // one LDS block: the two double-buffered operand tiles, reused as the epilogue's transpose patches
-    __shared__ __attribute__((aligned(16))) float lds_raw[2 * BK * (BM + BN)];
+    constexpr int A_V4 = BK * BM / 4, B_V4 = BK * BN / 4;                  // 16-byte pieces of one operand tile
+    constexpr int A_LD = (A_V4 + NT - 1) / NT, B_LD = (B_V4 + NT - 1) / NT;
+    static_assert(A_V4 % NT == 0 && B_V4 % NT == 0, "operand tiles must be a whole number of passes");
     float (*As)[BK][BM] = reinterpret_cast<float (*)[BK][BM]>(lds_raw);
     float (*Bs)[BK][BN] = reinterpret_cast<float (*)[BK][BN]>(lds_raw + 2 * BK * BM);
-
-    TN_STAMP(0);
-    const unsigned logical = hpcs_xcd_remap(blockIdx.x, total);
-    const int rowTile = logical % tilesM;
-    const unsigned t1 = logical / tilesM;
-    const int colTile = t1 % tilesN;
-    const int batch = t1 / tilesN;
-    const int bo = batch / n_inner, bi = batch % n_inner;
-    const float* Bp = Bm + bo * sBo + bi * sBi;
-    float* Cp = C + bo * sCo + bi * sCi;
-    const int m0 = rowTile * BM, n0 = colTile * BN;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -84,77 +73,62 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void gemm_tn_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // two register sets: set 0 is the one-step prefetch; PF == 2 uses set 1 for the second step in flight
-    f32x4 rA[PF][A_LD], rB[PF][B_LD];
-    // FAST loader state: per-thread column offsets are fixed, only the row advances
-    int colA[A_LD], colB[B_LD], rowA[A_LD], rowB[B_LD];
-    if constexpr (FAST) {
+    f32x4 rA[A_LD], rB[B_LD];
+    int rowA[A_LD], c4A[A_LD], rowB[B_LD], c4B[B_LD];
 #pragma unroll
-        for (int i = 0; i < A_LD; ++i) {
-            const int f = tid + i * NT;
-            rowA[i] = f / (BM / 4);
-            colA[i] = min(m0 + (f % (BM / 4)) * 4, lda - 4);
-        }
-#pragma unroll
-        for (int i = 0; i < B_LD; ++i) {
-            const int f = tid + i * NT;
-            rowB[i] = f / (BN / 4);
-            colB[i] = min(n0 + (f % (BN / 4)) * 4, Nc - 4);
-        }
+    for (int i = 0; i < A_LD; ++i) {
+        const int f = tid + i * NT;
+        rowA[i] = f / (BM / 4);
+        c4A[i] = (f % (BM / 4)) * 4;
     }
-    auto gload = [&](int k0, auto set) {
-        constexpr int S = decltype(set)::value;
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) {
+        const int f = tid + i * NT;
+        rowB[i] = f / (BN / 4);
+        c4B[i] = (f % (BN / 4)) * 4;
+    }
+    auto gload = [&](int k0) {
         if constexpr (FAST) {
 #pragma unroll
             for (int i = 0; i < A_LD; ++i)
-                rA[S][i] = *reinterpret_cast<const f32x4*>(At + (int64_t)min(k0 + rowA[i], K - 1) * lda + colA[i]);
+                rA[i] = *reinterpret_cast<const f32x4*>(At + (int64_t)min(k0 + rowA[i], K - 1) * lda + min(m0 + c4A[i], lda - 4));
 #pragma unroll
             for (int i = 0; i < B_LD; ++i)
-                rB[S][i] = *reinterpret_cast<const f32x4*>(Bp + (int64_t)min(k0 + rowB[i], K - 1) * ldb + colB[i]);
+                rB[i] = *reinterpret_cast<const f32x4*>(Bp + (int64_t)min(k0 + rowB[i], K - 1) * ldb + min(n0 + c4B[i], Nc - 4));
         } else {
 #pragma unroll
             for (int i = 0; i < A_LD; ++i) {
-                const int f = tid + i * NT, row = f / (BM / 4), c4 = (f % (BM / 4)) * 4;
-                const float4 q = ld4_guard(At + (int64_t)(k0 + row) * lda, m0 + c4, M, k0 + row < K, vecA);
-                rA[S][i] = f32x4{q.x, q.y, q.z, q.w};
+                const float4 q = ld4_guard(At + (int64_t)(k0 + rowA[i]) * lda, m0 + c4A[i], M, k0 + rowA[i] < K, vecA);
+                rA[i] = f32x4{q.x, q.y, q.z, q.w};
             }
 #pragma unroll
             for (int i = 0; i < B_LD; ++i) {
-                const int f = tid + i * NT, row = f / (BN / 4), c4 = (f % (BN / 4)) * 4;
-                const float4 q = ld4_guard(Bp + (int64_t)(k0 + row) * ldb, n0 + c4, Nc, k0 + row < K, vecB);
-                rB[S][i] = f32x4{q.x, q.y, q.z, q.w};
+                const float4 q = ld4_guard(Bp + (int64_t)(k0 + rowB[i]) * ldb, n0 + c4B[i], Nc, k0 + rowB[i] < K, vecB);
+                rB[i] = f32x4{q.x, q.y, q.z, q.w};
             }
         }
     };
-    auto lstore = [&](int buf, int k0, auto set) {
-        constexpr int S = decltype(set)::value;
+    auto lstore = [&](int buf, int k0) {
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
-            const int f = tid + i * NT, row = f / (BM / 4), c4 = (f % (BM / 4)) * 4;
-            f32x4 v = rA[S][i];
-            // FAST: rows beyond K (last K step) are zeroed in A -- B's are finite copies of row K-1, their products vanish
+            f32x4 v = rA[i];
             if constexpr (FAST) {
-                if (k0 + row >= K) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (k0 + rowA[i] >= K) v = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            *reinterpret_cast<f32x4*>(&As[buf][row][c4]) = v;
+            *reinterpret_cast<f32x4*>(&As[buf][rowA[i]][c4A[i]]) = v;
         }
 #pragma unroll
-        for (int i = 0; i < B_LD; ++i) {
-            const int f = tid + i * NT, row = f / (BN / 4), c4 = (f % (BN / 4)) * 4;
-            *reinterpret_cast<f32x4*>(&Bs[buf][row][c4]) = rB[S][i];
-        }
+        for (int i = 0; i < B_LD; ++i) *reinterpret_cast<f32x4*>(&Bs[buf][rowB[i]][c4B[i]]) = rB[i];
     };
-    constexpr std::integral_constant<int, 0> S0{};
-    constexpr std::integral_constant<int, PF - 1> S1{};
 
     const int nk = (K + BK - 1) / BK;
-    gload(0, S0);
-    lstore(0, 0, S0);
+    gload(0);
+    lstore(0, 0);
     __syncthreads();
     TN_STAMP(1);
     const int lr = lane & 31, lk = lane >> 5;
-    // 32x32 sub-tiles that lie entirely in the padding of an edge tile (M = 341 / 682 leave 32-64 dead rows in the last
-    // 128-row tile) issue no MFMA: the matrix pipe of that SIMD goes to the other resident workgroup instead
+    // 32x32 sub-tiles that lie entirely in the padding of an edge tile issue no MFMA: the matrix pipe of that SIMD goes to
+    // the other resident workgroups instead
     bool live[TM][TN];
     bool all_live = true;
 #pragma unroll
@@ -180,39 +154,16 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void gemm_tn_kernel(
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     };
-    if constexpr (PF == 1) {
-        for (int kt = 0; kt < nk; ++kt) {
-            const int buf = kt & 1;
-            if (kt + 1 < nk) gload((kt + 1) * BK, S0);
-            if (all_live) mma(buf, std::true_type{});
-            else mma(buf, std::false_type{});
-            if (kt + 1 < nk) lstore(buf ^ 1, (kt + 1) * BK, S0);
-            __syncthreads();
-        }
-    } else {
-        // Two K steps of prefetch distance: while the MFMAs of step kt run from LDS, the registers of step kt+1 (requested one
-        // iteration ago) are stored to the other LDS buffer and step kt+2 is requested into the second register set -- a
-        // global load has a whole iteration (not just one MFMA group) to arrive before `vmcnt` waits for it.
-        if (nk > 1) gload(BK, S0);                                // step 1 -> set 0
-        for (int kt = 0; kt < nk; kt += 2) {
-            // even step: LDS buffer 0 holds kt, set 0 holds kt+1, request kt+2 into set 1
-            if (kt + 2 < nk) gload((kt + 2) * BK, S1);
-            if (all_live) mma(0, std::true_type{});
-            else mma(0, std::false_type{});
-            if (kt + 1 < nk) lstore(1, (kt + 1) * BK, S0);
-            __syncthreads();
-            if (kt + 1 >= nk) break;
-            // odd step: LDS buffer 1 holds kt+1, set 1 holds kt+2, request kt+3 into set 0
-            if (kt + 3 < nk) gload((kt + 3) * BK, S0);
-            if (all_live) mma(1, std::true_type{});
-            else mma(1, std::false_type{});
-            if (kt + 2 < nk) lstore(0, (kt + 2) * BK, S1);
-            __syncthreads();
-        }
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload((kt + 1) * BK);
+        if (all_live) mma(buf, std::true_type{});
+        else mma(buf, std::false_type{});
+        if (kt + 1 < nk) lstore(buf ^ 1, (kt + 1) * BK);
+        __syncthreads();
     }
 
     TN_STAMP(2);
-    const float* bias = rowbias ? rowbias + (int64_t)batch * M : nullptr;
     if (vecC) {
         // Epilogue through a wave-private LDS patch: the MFMA result holds 4-row x 1-column slivers per lane, i.e. one
         // dword store per register (two 128-byte row segments per wave instruction).  Transposed through LDS each lane
@@ -274,6 +225,31 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void gemm_tn_kernel(
                 }
             }
         }
+}
+
+// Measured and NOT kept: a last row tile of 64 / 96 rows with its four waves side by side (M = 341 / 682 leave 43 / 86 dead
+// rows in a 128-row last tile whose lower waves then issue no MFMA): 491 vs 488 us, 416 vs 421 us -- the other resident
+// workgroups already use the matrix-pipe time the dead waves leave.
+template <int BM, int BN, int BK, int WM, int WN, bool FAST>
+__global__ __launch_bounds__(WM* WN * 64, 4) void gemm_tn_kernel(
+    const float* __restrict__ At, int lda, const float* __restrict__ Bm, int ldb, int64_t sBo, int64_t sBi,
+    float* __restrict__ C, int ldc, int64_t sCo, int64_t sCi, int M, int Nc, int K, int n_inner,
+    const float* __restrict__ rowbias, int accumulate, int tilesM, int tilesN, unsigned total, int vecA,
+    int vecB, int vecC) {
+    // one LDS block: the two double-buffered operand tiles, reused as the epilogue's transpose patches
+    __shared__ __attribute__((aligned(16))) float lds_raw[2 * BK * (BM + BN)];
+    TN_STAMP(0);
+    const unsigned logical = hpcs_xcd_remap(blockIdx.x, total);
+    const int rowTile = logical % tilesM;
+    const unsigned t1 = logical / tilesM;
+    const int colTile = t1 % tilesN;
+    const int batch = t1 / tilesN;
+    const int bo = batch / n_inner, bi = batch % n_inner;
+    const float* Bp = Bm + bo * sBo + bi * sBi;
+    float* Cp = C + bo * sCo + bi * sCi;
+    const float* bias = rowbias ? rowbias + (int64_t)batch * M : nullptr;
+    const int m0 = rowTile * BM, n0 = colTile * BN;
+    tn_tile<BM, BN, BK, WM, WN, FAST>(At, lda, Bp, ldb, Cp, ldc, M, Nc, K, bias, accumulate, m0, n0, vecA, vecB, vecC, lds_raw);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -721,38 +697,27 @@ extern "C" int hpcs_gemm_tn(const float* At, int lda, const float* Bm, int ldb, 
             return HPCS_OK;
         }
     }
-    // straight-line loader: every 16-byte load of both operands is in bounds after clamping (see gemm_tn_kernel)
+    // straight-line loader: every 16-byte load of both operands is in bounds after clamping (see tn_tile)
     const bool fast = vecA && vecB && Nc % 4 == 0 && Nc >= 4 && lda >= 4;
+    // A/B switch: HPCS_GEMM_TN_GUARDED=1 forces the guarded loader
+    static int guarded = -1;
+    if (guarded < 0) { const char* e = getenv("HPCS_GEMM_TN_GUARDED"); guarded = e ? atoi(e) != 0 : 0; }
+#define HPCS_TN_LAUNCH(BM_, WM_, WN_, FAST_)                                                                                 \
+    hipLaunchKernelGGL((gemm_tn_kernel<BM_, 128, 16, WM_, WN_, FAST_>), dim3((unsigned)total), dim3(256), 0, st, At, lda, Bm,     \
+                       ldb, strideB_o, strideB_i, C, ldc, strideC_o, strideC_i, M, Nc, K, n_inner, rowbias, accumulate, tm, tn,  \
+                       (unsigned)total, vecA, vecB, vecC)
+    const int BMsel = M > 64 ? 128 : 64;
+    const int tm = hpcs_cdiv(M, BMsel), tn = hpcs_cdiv(Nc, 128);
+    const long total = (long)tm * tn * nb;
+    if (total > 0x7fffffffL) return HPCS_ERR_UNSUPPORTED;
     if (M > 64) {
-        constexpr int BM = 128, BN = 128, BK = 16;
-        const int tm = hpcs_cdiv(M, BM), tn = hpcs_cdiv(Nc, BN);
-        const long total = (long)tm * tn * nb;
-        if (total > 0x7fffffffL) return HPCS_ERR_UNSUPPORTED;
-        // HPCS_GEMM_TN_VAR (A/B switch): 0 = default (straight-line loader where the operands allow it), 1 = guarded loader
-        static int var = -1;
-        if (var < 0) { const char* e = getenv("HPCS_GEMM_TN_VAR"); var = e ? atoi(e) : 0; }
-        if (fast && var != 1)
-            hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, BK, 2, 2, 1, 4, true>), dim3((unsigned)total), dim3(256), 0, st, At, lda, Bm,
-                               ldb, strideB_o, strideB_i, C, ldc, strideC_o, strideC_i, M, Nc, K, n_inner, rowbias,
-                               accumulate, tm, tn, (unsigned)total, vecA, vecB, vecC);
-        else
-            hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, BK, 2, 2, 1, 4, false>), dim3((unsigned)total), dim3(256), 0, st, At, lda, Bm,
-                               ldb, strideB_o, strideB_i, C, ldc, strideC_o, strideC_i, M, Nc, K, n_inner, rowbias,
-                               accumulate, tm, tn, (unsigned)total, vecA, vecB, vecC);
+        if (fast && !guarded) HPCS_TN_LAUNCH(128, 2, 2, true);
+        else HPCS_TN_LAUNCH(128, 2, 2, false);
     } else {
-        constexpr int BM = 64, BN = 128, BK = 16;
-        const int tm = hpcs_cdiv(M, BM), tn = hpcs_cdiv(Nc, BN);
-        const long total = (long)tm * tn * nb;
-        if (total > 0x7fffffffL) return HPCS_ERR_UNSUPPORTED;
-        if (fast)
-            hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, BK, 1, 4, 1, 4, true>), dim3((unsigned)total), dim3(256), 0, st, At, lda, Bm,
-                               ldb, strideB_o, strideB_i, C, ldc, strideC_o, strideC_i, M, Nc, K, n_inner, rowbias,
-                               accumulate, tm, tn, (unsigned)total, vecA, vecB, vecC);
-        else
-            hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, BK, 1, 4, 1, 4, false>), dim3((unsigned)total), dim3(256), 0, st, At, lda, Bm,
-                               ldb, strideB_o, strideB_i, C, ldc, strideC_o, strideC_i, M, Nc, K, n_inner, rowbias,
-                               accumulate, tm, tn, (unsigned)total, vecA, vecB, vecC);
+        if (fast && !guarded) HPCS_TN_LAUNCH(64, 1, 4, true);
+        else HPCS_TN_LAUNCH(64, 1, 4, false);
     }
+#undef HPCS_TN_LAUNCH
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;
 }
