@@ -7,8 +7,9 @@ from concurrent.futures import ThreadPoolExecutor
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libhpcs_mi355x.so")
 ARCH = "gfx950"
-# per-file extra flags: knn.hip pins an exact fp32 rounding sequence, decode.hip scipy's fp64 cosine sequence
-EXTRA = {"knn.hip": ["-ffp-contract=off"], "decode.hip": ["-ffp-contract=off"]}
+# per-file extra flags: knn.hip pins an exact fp32 rounding sequence (and keeps its MFMA results in VGPRs: every score is
+# consumed by VALU code, an AGPR result costs one v_accvgpr_read each), decode.hip scipy's fp64 cosine sequence
+EXTRA = {"knn.hip": ["-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form"], "decode.hip": ["-ffp-contract=off"]}
 
 
 def _sources():

@@ -25,6 +25,8 @@
 // [D,N] slab is walked in candidate tiles of TC points (256 for D=3, 128 otherwise) staged in LDS as [D+1][TC] (row D = sq):
 // global reads are coalesced along N, LDS reads in the scoring loop are wave-uniform broadcasts.
 // Each thread keeps its sorted top-KK list in registers (static indexing only).
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -248,18 +250,38 @@ __global__ __launch_bounds__(MW * 64) void knn_mfma_kernel(const float* __restri
 // 64-bit key (order-preserving image of the float in the high word, ~index in the low word: larger key = better, ties
 // to the smaller index), the tile's 16 keys are sorted by a bitonic network (80 compare-exchanges of 5 instructions) and
 // merged with the sorted list by the classic max(A[i], B[31-i]) + bitonic-merge step (16 + 80 compare-exchanges).
-__device__ __forceinline__ unsigned long long knn_key(float s, int j) {
+// The key is held as a DOUBLE: K = hi32 * 2^20 + (2^20 - 1 - j) < 2^52 placed in the mantissa of a number in [2^52, 2^53)
+// (bit pattern 0x433.. | K: four integer instructions, no conversion), so keys order like the integers K and a
+// compare-exchange is v_max_f64 + v_min_f64 -- measured 9.8 SIMD cycles against 51.5 for v_cmp_gt_u64 + four v_cndmask
+// (64-bit integer compares are slow on this chip) and 36.6 for split 32-bit compares (scratch/ce_bench.hip).  Needs
+// j < 2^20 (hpcs_knn sends larger clouds to the scalar kernel).
+__device__ __forceinline__ double knn_key(float s, int j) {
     const unsigned u = __float_as_uint(s + 0.0f);                      // -0 -> +0: equal scores must give equal high words
     const unsigned hi = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-    return ((unsigned long long)hi << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)j);
+    const unsigned lo20 = 0xFFFFFu - (unsigned)j;                      // j < 2^20
+    return __hiloint2double((int)(0x43300000u | (hi >> 12)), (int)((hi << 20) | lo20));
 }
-#define KNN_CE(a, b)                                                   \
-    {                                                                  \
-        const unsigned long long x_ = (a), y_ = (b);                   \
-        const bool sw_ = y_ > x_;                                      \
-        (a) = sw_ ? y_ : x_;                                           \
-        (b) = sw_ ? x_ : y_;                                           \
-    }
+__device__ __forceinline__ double knn_key_worst() {                    // score -inf, below every real index
+    const unsigned hi = ~0xFF800000u;
+    return __hiloint2double((int)(0x43300000u | (hi >> 12)), (int)(hi << 20));
+}
+__device__ __forceinline__ int knn_key_index(double key) { return (int)(0xFFFFFu - ((unsigned)__double2loint(key) & 0xFFFFFu)); }
+__device__ __forceinline__ float knn_key_score(double key) {
+    const unsigned hi = (((unsigned)__double2hiint(key) & 0xFFFFFu) << 12) | ((unsigned)__double2loint(key) >> 20);
+    return __uint_as_float((hi & 0x80000000u) ? (hi ^ 0x80000000u) : ~hi);
+}
+__device__ __forceinline__ void knn_ce(double& a, double& b) {        // a = better (larger), b = worse
+    double mx, mn;
+    asm("v_max_f64 %0, %2, %3\n\tv_min_f64 %1, %2, %3" : "=&v"(mx), "=&v"(mn) : "v"(a), "v"(b));
+    a = mx;
+    b = mn;
+}
+__device__ __forceinline__ double knn_max(double a, double b) {
+    double mx;
+    asm("v_max_f64 %0, %1, %2" : "=v"(mx) : "v"(a), "v"(b));
+    return mx;
+}
+#define KNN_CE(a, b) knn_ce((a), (b));
 
 // k > KK (k = 33..40 on the 32-wide lists): a query's k nearest are merged from 8 sub-lists of 32, which is exact unless one
 // sub-list would have contributed MORE than its 32 entries -- then (and only then) the merge exhausts that sub-list, the
@@ -269,7 +291,7 @@ template <int KSTEPS, int KK>
 __global__ __launch_bounds__(MW * 64) void knn_mfma_sort_kernel(const float* __restrict__ x, const float* __restrict__ sq, int D,
                                                                 int N, int k, int64_t* __restrict__ idx, int* __restrict__ redo) {
     static_assert(KK <= 32, "the merge network is 32 wide");
-    __shared__ unsigned long long lkey[MQ][2 * MW][KK];
+    __shared__ double lkey[MQ][2 * MW][KK];
     const int tiles_q = (N + MQ - 1) / MQ;
     const int b = blockIdx.x / tiles_q;
     const int q0 = (blockIdx.x % tiles_q) * MQ;
@@ -286,8 +308,8 @@ __global__ __launch_bounds__(MW * 64) void knn_mfma_sort_kernel(const float* __r
         bq[kk] = (qok && d < D) ? xb[(int64_t)d * N + qi] : 0.f;
     }
     const float sq_i = qok ? sqb[qi] : 0.f;
-    const unsigned long long WORST = knn_key(-INFINITY, 0x7fffffff);
-    unsigned long long lst[32];                                        // sorted, best first; entries >= KK stay WORST
+    const double WORST = knn_key_worst();
+    double lst[32];                                        // sorted, best first; entries >= KK stay WORST
 #pragma unroll
     for (int m = 0; m < 32; ++m) lst[m] = WORST;
 
@@ -307,8 +329,8 @@ __global__ __launch_bounds__(MW * 64) void knn_mfma_sort_kernel(const float* __r
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
         for (int kk = 0; kk < KSTEPS; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk], bq[kk], acc, 0, 0, 0);
-        unsigned long long key[16];
-        unsigned long long best = WORST;
+        double key[16];
+        double best = WORST;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int j = c0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
@@ -317,7 +339,7 @@ __global__ __launch_bounds__(MW * 64) void knn_mfma_sort_kernel(const float* __r
             const float tt = (-sq_j) - inner;
             const float sc = j < N ? tt - sq_i : -INFINITY;
             key[r] = j < N ? knn_key(sc, j) : WORST;
-            best = key[r] > best ? key[r] : best;
+            best = knn_max(key[r], best);
         }
         if (!__any(best > lst[KK - 1])) continue;                      // nothing in this tile reaches any list of the wave
         // bitonic sort of the 16 keys, best first
@@ -335,8 +357,7 @@ __global__ __launch_bounds__(MW * 64) void knn_mfma_sort_kernel(const float* __r
         // the 32 best of list (32, padded) and tile (16, padded to 32): C[i] = max(A[i], B[31 - i]) is bitonic
 #pragma unroll
         for (int i = 16; i < 32; ++i) {
-            const unsigned long long bkey = key[31 - i];
-            lst[i] = bkey > lst[i] ? bkey : lst[i];
+            lst[i] = knn_max(key[31 - i], lst[i]);
         }
         // bitonic merge, best first
 #pragma unroll
@@ -359,17 +380,17 @@ __global__ __launch_bounds__(MW * 64) void knn_mfma_sort_kernel(const float* __r
         for (int u = 0; u < 2 * MW; ++u) head[u] = 0;
         int64_t* o = idx + ((int64_t)b * N + q0 + q) * k;
         for (int m = 0; m < k; ++m) {
-            unsigned long long bestk = 0ull;
+            double bestk = 0.0;
             int bu = 0;
 #pragma unroll
             for (int u = 0; u < 2 * MW; ++u) {
                 const int h = head[u];
-                const unsigned long long v = h < KK ? lkey[q][u][h] : 0ull;
+                const double v = h < KK ? lkey[q][u][h] : 0.0;
                 if (v > bestk) { bestk = v; bu = u; }
             }
 #pragma unroll
             for (int u = 0; u < 2 * MW; ++u) head[u] += (u == bu) ? 1 : 0;
-            o[m] = (int64_t)(0xFFFFFFFFu - (unsigned)(bestk & 0xFFFFFFFFull));
+            o[m] = (int64_t)knn_key_index(bestk);
         }
         if (redo && k > KK) {
             bool exhausted = false;
@@ -516,6 +537,173 @@ __global__ __launch_bounds__(NW * 64) void knn_mfma_queue_kernel(const float* __
     }
 }
 
+// Batch-queue variant (k <= 32): the queued kernel's layout (one wave = 32 queries x ALL candidate tiles, two lists per query:
+// the lane halves) with the sorting-network kernel's list handling.  A score that can still enter the query's k best is only
+// APPENDED (score bits + index) to a per-lane LDS ring; when some lane holds more than 16 pending keys the wave sorts 16 per
+// lane with the bitonic network and merges them into the 32-wide sorted lists in one pass (~950 instructions per 16 keys per
+// lane, against 16 serial insertions of ~120 in the queued kernel, and against one network pass per TILE in the 4-wave
+// kernel, whose 8 short lists per query let nearly every tile through).  The admission threshold is the better of the two
+// lists' k-th keys of the query (exchanged between lane l and l+32 after every merge): a key below the OTHER list's k-th key
+// has k better keys ahead of it there, so it cannot be among the query's k best -- exact in the (score, index) order, ties
+// included.  Thresholds are stale between merges (a superset is queued); the merge itself decides.  Expected per list of 512
+// candidates: ~60-100 appended keys, ~8-12 merges per wave.
+constexpr int BQ_RING = 32;    // ring slots per lane: a tile appends at most 16, a merge takes 16
+template <int KSTEPS, int KK>
+__global__ __launch_bounds__(64) void knn_mfma_bq_kernel(const float* __restrict__ x, const float* __restrict__ sq, int D, int N,
+                                                        int k, int64_t* __restrict__ idx) {
+    static_assert(KK <= 32, "the merge network is 32 wide");
+    __shared__ int2 ring[BQ_RING][64];                     // (score bits, index); 16 KB, reused for the final two-list merge
+    const int tiles_q = (N + MQ - 1) / MQ;
+    const int b = blockIdx.x / tiles_q;
+    const int q0 = (blockIdx.x % tiles_q) * MQ;
+    const int lane = threadIdx.x & 63;
+    const int lr = lane & 31, lk = lane >> 5;
+    const float* xb = x + (int64_t)b * D * N;
+    const float* sqb = sq + (int64_t)b * N;
+    const int qi = q0 + lr;
+    const bool qok = qi < N;
+    float bq[KSTEPS];
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; ++kk) {
+        const int d = 2 * kk + lk;
+        bq[kk] = (qok && d < D) ? xb[(int64_t)d * N + qi] : 0.f;
+    }
+    const float sq_i = qok ? sqb[qi] : 0.f;
+    const double WORST = knn_key_worst();
+    double lst[32];                                        // sorted, best first; entries >= KK stay WORST
+#pragma unroll
+    for (int m = 0; m < 32; ++m) lst[m] = WORST;
+    float thr_f = -INFINITY;                                           // admission threshold (inclusive: a superset is queued)
+    int head = 0, tail = 0;                                            // ring positions of this lane (slot = pos & 31)
+
+    auto merge16 = [&]() {
+        const int n = min(tail - head, 16);
+        double key[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int2 v = ring[(head + r) & (BQ_RING - 1)][lane];
+            key[r] = r < n ? knn_key(__int_as_float(v.x), v.y) : WORST;
+        }
+        head += n;
+#pragma unroll
+        for (int kb = 2; kb <= 16; kb <<= 1)
+#pragma unroll
+            for (int jb = kb >> 1; jb > 0; jb >>= 1)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int l = i ^ jb;
+                    if (l > i) {
+                        if ((i & kb) == 0) { KNN_CE(key[i], key[l]) } else { KNN_CE(key[l], key[i]) }
+                    }
+                }
+#pragma unroll
+        for (int i = 16; i < 32; ++i) {
+            lst[i] = knn_max(key[31 - i], lst[i]);
+        }
+#pragma unroll
+        for (int jb = 16; jb > 0; jb >>= 1)
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const int l = i ^ jb;
+                if (l > i) { KNN_CE(lst[i], lst[l]) }
+            }
+#pragma unroll
+        for (int m = KK; m < 32; ++m) lst[m] = WORST;
+        // Admission threshold of the query: any key with KK keys ahead of it in the two lists together is out.  Valid lower
+        // bounds of the union's KK-th key: either list's own KK-th key, and min(A[i-1], B[j-1]) for i + j = KK (i keys of
+        // one list and j of the other are ahead).  With i ~ j ~ KK/2 the bound is tight from the first merge on (each
+        // list holds 16 keys then), where the lists' own KK-th keys do not exist yet: 104 -> 77 queued keys per lane.
+        constexpr int HI = (KK + 1) / 2, HJ = KK - HI;
+        auto partner = [&](double v) {
+            return __hiloint2double(__shfl_xor(__double2hiint(v), 32), __shfl_xor(__double2loint(v), 32));
+        };
+        const double p_last = partner(lst[KK - 1]), p_i = partner(lst[HI - 1]), p_j = HI == HJ ? p_i : partner(lst[HJ - 1]);
+        double b1, b2;
+        asm("v_min_f64 %0, %1, %2" : "=v"(b1) : "v"(lst[HI - 1]), "v"(p_j));
+        asm("v_min_f64 %0, %1, %2" : "=v"(b2) : "v"(lst[HJ - 1]), "v"(p_i));
+        const double thr_key = knn_max(knn_max(lst[KK - 1], p_last), knn_max(b1, b2));
+        thr_f = knn_key_score(thr_key);
+    };
+
+    const int ntile = (N + 31) / 32;
+    const bool sq_vec = (N % 4 == 0) && ((((uintptr_t)sq) & 15u) == 0);
+    float af[KSTEPS];
+    {
+        const int ci = lr;
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) {
+            const int d = 2 * kk + lk;
+            af[kk] = (ci < N && d < D) ? xb[(int64_t)d * N + ci] : 0.f;
+        }
+    }
+    for (int t = 0; t < ntile; ++t) {
+        const int c0 = t * 32;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk], bq[kk], acc, 0, 0, 0);
+        if (t + 1 < ntile) {                       // next tile's candidate operand is in flight during the selection
+            const int ci = c0 + 32 + lr;
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk) {
+                const int d = 2 * kk + lk;
+                af[kk] = (ci < N && d < D) ? xb[(int64_t)d * N + ci] : 0.f;
+            }
+        }
+        float sqj[16];
+        const bool full = c0 + 32 <= N;
+        if (full && sq_vec) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 v = *reinterpret_cast<const float4*>(sqb + c0 + 8 * g + 4 * lk);
+                sqj[4 * g] = v.x; sqj[4 * g + 1] = v.y; sqj[4 * g + 2] = v.z; sqj[4 * g + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = c0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                sqj[r] = j < N ? sqb[j] : 0.f;
+            }
+        }
+        auto scan = [&](auto whole) {              // whole tile inside the cloud: no per-candidate bound test
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = c0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                const float inner = -2.0f * acc[r];
+                const float tt = (-sqj[r]) - inner;
+                const float sc = tt - sq_i;
+                if ((decltype(whole)::value || j < N) && sc >= thr_f) {
+                    ring[tail & (BQ_RING - 1)][lane] = make_int2(__float_as_int(sc), j);
+                    ++tail;
+                }
+            }
+        };
+        if (full) scan(std::true_type{});
+        else scan(std::false_type{});
+        if (__any(tail - head > 16)) merge16();    // afterwards every lane holds <= 16: room for the next tile
+    }
+    while (__any(tail > head)) merge16();
+    // two sorted lists per query (lanes l, l + 32) -> LDS -> one thread per query merges
+    double (*lkey)[2][32] = reinterpret_cast<double (*)[2][32]>(&ring[0][0]);          // (all pending keys are merged)
+#pragma unroll
+    for (int m = 0; m < KK; ++m) lkey[lr][lk][m] = lst[m];
+    __syncthreads();
+    if (lane < MQ && q0 + lane < N) {
+        int h0 = 0, h1 = 0;
+        int64_t* o = idx + ((int64_t)b * N + q0 + lane) * k;
+        for (int m = 0; m < k; ++m) {
+            const double a = h0 < KK ? lkey[lane][0][h0] : 0.0;
+            const double c = h1 < KK ? lkey[lane][1][h1] : 0.0;
+            const bool ta = a > c;
+            const double bestk = ta ? a : c;
+            h0 += ta ? 1 : 0;
+            h1 += ta ? 0 : 1;
+            o[m] = (int64_t)knn_key_index(bestk);
+        }
+    }
+}
+
 template <int KSTEPS>
 int launch_knn_mfma(const float* x, const float* sq, int B, int D, int N, int k, int64_t* idx, int* redo, hipStream_t st) {
     const int tiles_q = (N + MQ - 1) / MQ;
@@ -527,9 +715,12 @@ int launch_knn_mfma(const float* x, const float* sq, int B, int D, int N, int k,
     // and for N = 2048, k = 40 (lists longer than the 32-wide merge network): queued 390-500 us, insertion 817-894 us;
     // r02: sorting network on 32-wide lists + flagged exact repair (see knn_mfma_sort_kernel): measured below.
     // So: k <= 32 -> sorting network; 32 < k <= 40 -> sorting network with 32-wide lists + repair pass of the queued kernel.
-    const char* e = getenv("HPCS_KNN_KERNEL");     // tiled|queue overrides the choice (A/B tests; read on every call)
-    const int force = !e ? 0 : (e[0] == 't' ? 1 : (e[0] == 'i' ? 3 : 2));      // tiled (sorting network) | insert | queue
+    const char* e = getenv("HPCS_KNN_KERNEL");     // tiled|insert|queue|bq overrides the choice (A/B tests; read on every call)
+    const int force = !e ? 0 : (e[0] == 't' ? 1 : (e[0] == 'i' ? 3 : (e[0] == 'b' ? 4 : 2)));  // tiled (sorting network) | insert | bq | queue
     const bool tiled = force == 1 || force == 3 || (force == 0 && k <= 32);
+    // k <= 32: the batch-queue kernel (one wave per 32 queries) once there is a wave per SIMD, the 4-wave sorting-network
+    // kernel for small batches (B=8, N=500: 32 vs 58 us; B=32, N=1024: 60 vs 60 (D=3), 132 vs 118 (D=63); B=4096: 5215 vs 3316)
+    const bool bq = force == 4 || (force == 0 && k <= 32 && (long)grid.x >= 1024);
     if (k > 32 && redo && (force == 0 || force == 1)) {
         if (hipMemsetAsync(redo, 0, sizeof(int) * grid.x, st) != hipSuccess) return HPCS_ERR_HIP;
         hipLaunchKernelGGL((knn_mfma_sort_kernel<KSTEPS, 32>), grid, dim3(MW * 64), 0, st, x, sq, D, N, k, idx, redo);
@@ -538,7 +729,9 @@ int launch_knn_mfma(const float* x, const float* sq, int B, int D, int N, int k,
     }
 #define HPCS_KNNM_CASE(KK)                                                                                   \
     if (k <= KK) {                                                                                            \
-        if (tiled && KK <= 32 && force != 3)                                                                  \
+        if (bq && KK <= 32)                                                                                   \
+            hipLaunchKernelGGL((knn_mfma_bq_kernel<KSTEPS, (KK <= 32 ? KK : 32)>), grid, dim3(64), 0, st, x, sq, D, N, k, idx); \
+        else if (tiled && KK <= 32 && force != 3)                                                                  \
             hipLaunchKernelGGL((knn_mfma_sort_kernel<KSTEPS, (KK <= 32 ? KK : 32)>), grid, dim3(MW * 64), 0, st, x, sq, D, N, k, \
                                idx, (int*)nullptr);                                                           \
         else if (tiled)                                                                                       \
@@ -601,7 +794,7 @@ extern "C" int hpcs_knn(const float* x, int B, int D, int N, int k, int64_t* idx
     if (B == 0) return HPCS_OK;
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if ((D == 3 || D == 63) && k <= 40 && ws) {
+    if ((D == 3 || D == 63) && k <= 40 && ws && N <= (1 << 20)) {      // (the double-held keys carry 20 index bits)
         if (ws_bytes < hpcs_knn_workspace(B, N)) return HPCS_ERR_WORKSPACE;
         float* sq = (float*)ws;
         const int64_t total = (int64_t)B * N;
