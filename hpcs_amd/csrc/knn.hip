@@ -142,6 +142,7 @@ __global__ __launch_bounds__(QT) void knn_kernel(const float* __restrict__ x, in
 }
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __global__ void knn_sumsq_kernel(const float* __restrict__ x, int D, int N, int64_t total, float* __restrict__ sq) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -271,8 +272,9 @@ __device__ __forceinline__ float knn_key_score(double key) {
     return __uint_as_float((hi & 0x80000000u) ? (hi ^ 0x80000000u) : ~hi);
 }
 __device__ __forceinline__ void knn_ce(double& a, double& b) {        // a = better (larger), b = worse
-    double mx, mn;
-    asm("v_max_f64 %0, %2, %3\n\tv_min_f64 %1, %2, %3" : "=&v"(mx), "=&v"(mn) : "v"(a), "v"(b));
+    double mx, mn;                                                     // (two statements: a half nobody reads is dropped)
+    asm("v_max_f64 %0, %1, %2" : "=v"(mx) : "v"(a), "v"(b));
+    asm("v_min_f64 %0, %1, %2" : "=v"(mn) : "v"(a), "v"(b));
     a = mx;
     b = mn;
 }
@@ -547,7 +549,7 @@ __global__ __launch_bounds__(NW * 64) void knn_mfma_queue_kernel(const float* __
 // has k better keys ahead of it there, so it cannot be among the query's k best -- exact in the (score, index) order, ties
 // included.  Thresholds are stale between merges (a superset is queued); the merge itself decides.  Expected per list of 512
 // candidates: ~60-100 appended keys, ~8-12 merges per wave.
-constexpr int BQ_RING = 32;    // ring slots per lane: a tile appends at most 16, a merge takes 16
+constexpr int BQ_RING = 32;    // pending slots per lane: a tile appends at most 16, a merge leaves at most 16
 template <int KSTEPS, int KK>
 __global__ __launch_bounds__(64) void knn_mfma_bq_kernel(const float* __restrict__ x, const float* __restrict__ sq, int D, int N,
                                                         int k, int64_t* __restrict__ idx) {
@@ -574,17 +576,23 @@ __global__ __launch_bounds__(64) void knn_mfma_bq_kernel(const float* __restrict
 #pragma unroll
     for (int m = 0; m < 32; ++m) lst[m] = WORST;
     float thr_f = -INFINITY;                                           // admission threshold (inclusive: a superset is queued)
-    int head = 0, tail = 0;                                            // ring positions of this lane (slot = pos & 31)
+    int cnt = 0;                                                       // pending entries of this lane: a STACK (slot = cnt)
 
     auto merge16 = [&]() {
-        const int n = min(tail - head, 16);
+        // the newest (up to) 16 pending entries: popping from the top needs no wrap-around and no compaction
+        const int n = min(cnt, 16), base = cnt - n;
         double key[16];
+        int2 raw[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) raw[r] = ring[base + r][lane];      // 16 reads in flight together (base <= 16)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(raw[r].x), "+v"(raw[r].y));     // (not sunk into the selects)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int2 v = ring[(head + r) & (BQ_RING - 1)][lane];
-            key[r] = r < n ? knn_key(__int_as_float(v.x), v.y) : WORST;
+            const double kr = knn_key(__int_as_float(raw[r].x), raw[r].y & 0xFFFFF);
+            key[r] = r < n ? kr : WORST;
         }
-        head += n;
+        cnt = base;
 #pragma unroll
         for (int kb = 2; kb <= 16; kb <<= 1)
 #pragma unroll
@@ -636,6 +644,27 @@ __global__ __launch_bounds__(64) void knn_mfma_bq_kernel(const float* __restrict
             af[kk] = (ci < N && d < D) ? xb[(int64_t)d * N + ci] : 0.f;
         }
     }
+    // |x_j|^2 of a tile's 16 candidate rows of this lane, requested one tile ahead (a dependent L2 round trip per tile
+    // otherwise: the scan cannot start before it)
+    float sqj[16], sqn[16];
+    auto load_sq = [&](int c0, float (&dst)[16]) {
+        if (c0 + 32 <= N && sq_vec) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 v = *reinterpret_cast<const float4*>(sqb + c0 + 8 * g + 4 * lk);
+                dst[4 * g] = v.x; dst[4 * g + 1] = v.y; dst[4 * g + 2] = v.z; dst[4 * g + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = c0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                dst[r] = j < N ? sqb[j] : 0.f;
+            }
+        }
+    };
+    load_sq(0, sqj);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sqn[r] = 0.f;
     for (int t = 0; t < ntile; ++t) {
         const int c0 = t * 32;
         f32x16 acc;
@@ -651,39 +680,34 @@ __global__ __launch_bounds__(64) void knn_mfma_bq_kernel(const float* __restrict
                 af[kk] = (ci < N && d < D) ? xb[(int64_t)d * N + ci] : 0.f;
             }
         }
-        float sqj[16];
         const bool full = c0 + 32 <= N;
-        if (full && sq_vec) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 v = *reinterpret_cast<const float4*>(sqb + c0 + 8 * g + 4 * lk);
-                sqj[4 * g] = v.x; sqj[4 * g + 1] = v.y; sqj[4 * g + 2] = v.z; sqj[4 * g + 3] = v.w;
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int j = c0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                sqj[r] = j < N ? sqb[j] : 0.f;
-            }
-        }
+        if (t + 1 < ntile) load_sq(c0 + 32, sqn);  // ... and its |x|^2 (the tile's own arrived during the previous tile)
         auto scan = [&](auto whole) {              // whole tile inside the cloud: no per-candidate bound test
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int j = c0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                const float inner = -2.0f * acc[r];
-                const float tt = (-sqj[r]) - inner;
-                const float sc = tt - sq_i;
-                if ((decltype(whole)::value || j < N) && sc >= thr_f) {
-                    ring[tail & (BQ_RING - 1)][lane] = make_int2(__float_as_int(sc), j);
-                    ++tail;
+            for (int r = 0; r < 16; r += 2) {
+                // two scores per packed instruction (v_pk_mul_f32 / v_pk_add_f32: IEEE per component, same roundings)
+                const f32x2 a2 = {acc[r], acc[r + 1]}, s2 = {sqj[r], sqj[r + 1]};
+                const f32x2 inner = a2 * -2.0f;
+                const f32x2 tt = (-s2) - inner;
+                const f32x2 sc2 = tt - sq_i;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int j = c0 + ((r + h) & 3) + 8 * ((r + h) >> 2) + 4 * lk;
+                    const float sc = h ? sc2.y : sc2.x;
+                    if ((decltype(whole)::value || j < N) && sc >= thr_f) {
+                        ring[cnt][lane] = make_int2(__float_as_int(sc), j);
+                        ++cnt;
+                    }
                 }
             }
         };
         if (full) scan(std::true_type{});
         else scan(std::false_type{});
-        if (__any(tail - head > 16)) merge16();    // afterwards every lane holds <= 16: room for the next tile
+        if (__any(cnt > 16)) merge16();            // afterwards every lane holds <= 16: room for the next tile's 16
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sqj[r] = sqn[r];
     }
-    while (__any(tail > head)) merge16();
+    while (__any(cnt > 0)) merge16();
     // two sorted lists per query (lanes l, l + 32) -> LDS -> one thread per query merges
     double (*lkey)[2][32] = reinterpret_cast<double (*)[2][32]>(&ring[0][0]);          // (all pending keys are merged)
 #pragma unroll
