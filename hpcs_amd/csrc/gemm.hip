@@ -43,6 +43,79 @@ __device__ __forceinline__ float4 ld4_guard(const float* __restrict__ rowp, int 
     return v;
 }
 
+// Epilogue of one tile: accumulators -> C (+ row bias, optional accumulate).  Callers guarantee that no wave still reads the
+// operand tiles in `lds_raw` (the main loop ends with a barrier).
+template <int BM, int BN, int BK, int WM, int WN>
+__device__ __forceinline__ void tn_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* __restrict__ Cp, int ldc, int M, int Nc,
+                                            const float* __restrict__ bias, int accumulate, int m0, int n0, int vecC,
+                                            float* lds_raw) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lr = lane & 31, lk = lane >> 5;
+    if (vecC) {
+        // Epilogue through a wave-private LDS patch: the MFMA result holds 4-row x 1-column slivers per lane, i.e. one
+        // dword store per register (two 128-byte row segments per wave instruction).  Transposed through LDS each lane
+        // owns 4 CONSECUTIVE columns instead and the tile leaves as 16-byte stores, eight 128-byte row segments per
+        // instruction -- the shape that streams at the HBM rate (the EdgeConv mixes write 330 MB per launch).
+        constexpr int PP = 36;                                   // patch pitch: 16-byte aligned rows, conflict-free
+        static_assert(2 * BK * (BM + BN) >= NT / 64 * 32 * PP, "patch does not fit");
+        float* patch = lds_raw + wave * (32 * PP);
+        // (the main loop ended with a barrier: nobody reads As / Bs any more)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row0 = m0 + wm * (BM / WM) + i * 32, col0 = n0 + wn * (BN / WN) + j * 32;
+                if (row0 >= M || col0 >= Nc) continue;           // wave-uniform
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    patch[((r & 3) + 8 * (r >> 2) + 4 * lk) * PP + lr] = acc[i][j][r];
+                __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0); the patch is wave-private: no barrier
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int rr = it * 8 + (lane >> 3), c4 = (lane & 7) * 4;
+                    const int row = row0 + rr, col = col0 + c4;
+                    if (row < M && col < Nc) {
+                        float4 v = *reinterpret_cast<const float4*>(patch + rr * PP + c4);
+                        if (bias) { const float bb = bias[row]; v.x += bb; v.y += bb; v.z += bb; v.w += bb; }
+                        float* dst = Cp + (int64_t)row * ldc + col;
+                        if (col + 3 < Nc) {
+                            if (accumulate) {
+                                const float4 o = *reinterpret_cast<const float4*>(dst);
+                                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                            }
+                            *reinterpret_cast<float4*>(dst) = v;
+                        } else {
+                            const float vv[4] = {v.x, v.y, v.z, v.w};
+                            for (int q = 0; q < 4 && col + q < Nc; ++q) dst[q] = accumulate ? dst[q] + vv[q] : vv[q];
+                        }
+                    }
+                }
+                __builtin_amdgcn_s_waitcnt(0xC07F);              // the reads are done before the next tile overwrites
+            }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * (BN / WN) + j * 32 + lr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (row < M && col < Nc) {
+                    float v = acc[i][j][r];
+                    if (bias) v += bias[row];
+                    float* dst = Cp + (int64_t)row * ldc + col;
+                    if (accumulate) v += *dst;
+                    *dst = v;
+                }
+            }
+        }
+}
+
 // One output tile of C = At^T * B: BM x BN, WM x WN waves of (BM/WM) x (BN/WN) each, BK-deep K steps, double-buffered LDS.
 // FAST: both operands are 16-byte loadable everywhere (lda, ldb, Nc multiples of 4, aligned bases): the loader is
 // straight-line code -- clamped addresses instead of guards (a clamped column only feeds output rows / columns that are never
@@ -164,67 +237,8 @@ __device__ __forceinline__ void tn_tile(const float* __restrict__ At, int lda, c
     }
 
     TN_STAMP(2);
-    if (vecC) {
-        // Epilogue through a wave-private LDS patch: the MFMA result holds 4-row x 1-column slivers per lane, i.e. one
-        // dword store per register (two 128-byte row segments per wave instruction).  Transposed through LDS each lane
-        // owns 4 CONSECUTIVE columns instead and the tile leaves as 16-byte stores, eight 128-byte row segments per
-        // instruction -- the shape that streams at the HBM rate (the EdgeConv mixes write 330 MB per launch).
-        constexpr int PP = 36;                                   // patch pitch: 16-byte aligned rows, conflict-free
-        static_assert(2 * BK * (BM + BN) >= NT / 64 * 32 * PP, "patch does not fit");
-        float* patch = lds_raw + wave * (32 * PP);
-        // (the main loop ended with a barrier: nobody reads As / Bs any more)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int row0 = m0 + wm * (BM / WM) + i * 32, col0 = n0 + wn * (BN / WN) + j * 32;
-                if (row0 >= M || col0 >= Nc) continue;           // wave-uniform
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    patch[((r & 3) + 8 * (r >> 2) + 4 * lk) * PP + lr] = acc[i][j][r];
-                __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0); the patch is wave-private: no barrier
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int rr = it * 8 + (lane >> 3), c4 = (lane & 7) * 4;
-                    const int row = row0 + rr, col = col0 + c4;
-                    if (row < M && col < Nc) {
-                        float4 v = *reinterpret_cast<const float4*>(patch + rr * PP + c4);
-                        if (bias) { const float bb = bias[row]; v.x += bb; v.y += bb; v.z += bb; v.w += bb; }
-                        float* dst = Cp + (int64_t)row * ldc + col;
-                        if (col + 3 < Nc) {
-                            if (accumulate) {
-                                const float4 o = *reinterpret_cast<const float4*>(dst);
-                                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-                            }
-                            *reinterpret_cast<float4*>(dst) = v;
-                        } else {
-                            const float vv[4] = {v.x, v.y, v.z, v.w};
-                            for (int q = 0; q < 4 && col + q < Nc; ++q) dst[q] = accumulate ? dst[q] + vv[q] : vv[q];
-                        }
-                    }
-                }
-                __builtin_amdgcn_s_waitcnt(0xC07F);              // the reads are done before the next tile overwrites
-            }
-        TN_STAMP(3);
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn * (BN / WN) + j * 32 + lr;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                if (row < M && col < Nc) {
-                    float v = acc[i][j][r];
-                    if (bias) v += bias[row];
-                    float* dst = Cp + (int64_t)row * ldc + col;
-                    if (accumulate) v += *dst;
-                    *dst = v;
-                }
-            }
-        }
+    tn_epilogue<BM, BN, BK, WM, WN>(acc, Cp, ldc, M, Nc, bias, accumulate, m0, n0, vecC, lds_raw);
+    TN_STAMP(3);
 }
 
 // Measured and NOT kept: a last row tile of 64 / 96 rows with its four waves side by side (M = 341 / 682 leave 43 / 86 dead
@@ -251,6 +265,10 @@ __global__ __launch_bounds__(WM* WN * 64, 4) void gemm_tn_kernel(
     const int m0 = rowTile * BM, n0 = colTile * BN;
     tn_tile<BM, BN, BK, WM, WN, FAST>(At, lda, Bp, ldb, Cp, ldc, M, Nc, K, bias, accumulate, m0, n0, vecA, vecB, vecC, lds_raw);
 }
+
+// Measured and NOT kept: a persistent form (min(tiles, 3-4 per CU) workgroups walk the tile list in the same XCD-aware order,
+// the next tile's first K step requested before the current tile's epilogue): vn1 forward 505-516 vs 496 us, EdgeConv mix
+// (K = 42) 150-156 vs 147 us -- four one-tile workgroups per CU already overlap each other's prologues and epilogues.
 
 // ---------------------------------------------------------------------------------------------------------
 // Small problems (a handful of MFMA tiles in total: row biases, [3B x C] frames): the tiled kernel would run on two
