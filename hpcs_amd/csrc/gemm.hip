@@ -681,6 +681,26 @@ __global__ void prep_weights_kernel(const float* __restrict__ W1, int ld1, int M
 
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
 
+// Point-level form of an EdgeConv layer's weights (VNGraphLayerFn.backward): W = [Wa | Wb] (difference | centre columns) ->
+// Wuv = [Wa ; Wb - Wa], and the way back for the gradient: dWa = gU-part - gV-part, dWb = gV-part, ADDED into the two
+// parameters' gradient slots (rows < Cout: map_to_feat, the rest: map_to_dir).  One launch each (was cat + sub + copy and
+// sub + cat + two adds of torch element-wise kernels per layer).
+__global__ void graph_wuv_kernel(const float* __restrict__ W, int ldw, int Ctot, int C, float* __restrict__ Wuv) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * Ctot * C) return;
+    const int r = i / C, c = i % C;
+    Wuv[i] = r < Ctot ? W[(int64_t)r * ldw + c] : W[(int64_t)(r - Ctot) * ldw + C + c] - W[(int64_t)(r - Ctot) * ldw + c];
+}
+__global__ void graph_wgrad_fold_kernel(const float* __restrict__ gWuv, int Ctot, int C, int Cout, float* __restrict__ gf,
+                                        float* __restrict__ gd) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Ctot * 2 * C) return;
+    const int r = i / (2 * C), c = i % (2 * C);
+    const float v = c < C ? gWuv[(int64_t)r * C + c] - gWuv[(int64_t)(Ctot + r) * C + c] : gWuv[(int64_t)(Ctot + r) * C + (c - C)];
+    float* dst = r < Cout ? gf + (int64_t)r * 2 * C + c : gd + (int64_t)(r - Cout) * 2 * C + c;
+    if (r < Cout ? gf != nullptr : gd != nullptr) *dst += v;
+}
+
 }  // namespace
 
 #ifdef HPCS_TN_STAMPS
@@ -801,6 +821,23 @@ extern "C" int hpcs_prep_weights(const float* W1, int ld1, int M1, const float* 
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(prep_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, W1, ld1, M1, W2, ld2, M2, K, At, lda,
                        Wp, ldp);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
+extern "C" int hpcs_graph_wuv(const float* W, int ldw, int Ctot, int C, float* Wuv, hpcs_stream_t stream) {
+    if (!W || !Wuv) return HPCS_ERR_NULL;
+    if (Ctot <= 0 || C <= 0 || ldw < 2 * C) return HPCS_ERR_SHAPE;
+    hipLaunchKernelGGL(graph_wuv_kernel, dim3(hpcs_cdiv(2 * Ctot * C, 256)), dim3(256), 0, (hipStream_t)stream, W, ldw, Ctot, C, Wuv);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
+extern "C" int hpcs_graph_wgrad_fold(const float* gWuv, int Ctot, int C, int Cout, float* gWf, float* gWd, hpcs_stream_t stream) {
+    if (!gWuv || (!gWf && !gWd)) return HPCS_ERR_NULL;
+    if (Ctot <= 0 || C <= 0 || Cout < 0 || Cout > Ctot) return HPCS_ERR_SHAPE;
+    hipLaunchKernelGGL(graph_wgrad_fold_kernel, dim3(hpcs_cdiv(Ctot * 2 * C, 256)), dim3(256), 0, (hipStream_t)stream, gWuv, Ctot, C,
+                       Cout, gWf, gWd);
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;
 }

@@ -363,6 +363,34 @@ __global__ __launch_bounds__(256) void colsum_pow2_kernel(const float* __restric
     }
 }
 
+// HypHC term, the scalar tail of the forward pass in one launch (was nine torch element-wise kernels):
+//   out = loss_sum / kept + (0.5 + 0.5 * |colsum|^2 / M^2)   (ultrametric_loss.py: HypHCSampledFn.forward)
+__global__ void hyphc_finalize_kernel(const double* __restrict__ loss_sum, const int64_t* __restrict__ kept,
+                                      const double* __restrict__ colsum, int64_t M, int E, float* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s = 0.0;
+    for (int e = 0; e < E; ++e) s += colsum[e] * colsum[e];
+    const double mean_sim = 0.5 + 0.5 * s / ((double)M * (double)M);
+    out[0] = (float)(loss_sum[0] / (double)kept[0] + mean_sim);
+}
+// ... and of the backward pass (ten): gxn = colsum / M^2 * g + gxn_raw * inv in place, gscale = gscale_raw * inv,
+// inv = g / max(kept, 1)
+__global__ __launch_bounds__(256) void hyphc_grad_finalize_kernel(const float* __restrict__ g, const int64_t* __restrict__ kept,
+                                                                 const double* __restrict__ colsum,
+                                                                 const double* __restrict__ gscale_raw, int64_t M, int E,
+                                                                 float* __restrict__ gxn, float* __restrict__ gscale) {
+    const float g32 = g[0];
+    const double k = (double)kept[0];
+    const float inv = (float)((double)g32 / (k < 1.0 ? 1.0 : k));
+    const int64_t total = M * E;
+    const double mm = (double)M * (double)M;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const float row = (float)(colsum[i % E] / mm) * g32;
+        gxn[i] = row + gxn[i] * inv;
+    }
+    if (gscale && blockIdx.x == 0 && threadIdx.x == 0) gscale[0] = (float)(gscale_raw[0] * (double)inv);
+}
+
 }  // namespace
 
 #define ST ((hipStream_t)stream)
@@ -499,6 +527,27 @@ extern "C" int hpcs_colsum(const float* xn, int64_t rows, int E, double* colsum,
         hipLaunchKernelGGL(colsum_pow2_kernel, dim3(hpcs_cdiv(rows, 256)), dim3(256), 0, ST, xn, rows, E, colsum);
     else
         hipLaunchKernelGGL(colsum_kernel, dim3(hpcs_cdiv(E, 64), hpcs_cdiv(rows, 1024)), dim3(256), 0, ST, xn, rows, E, colsum);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
+extern "C" int hpcs_hyphc_finalize(const double* loss_sum, const int64_t* kept, const double* colsum, int64_t M, int E, float* out,
+                                   hpcs_stream_t stream) {
+    if (!loss_sum || !kept || !colsum || !out) return HPCS_ERR_NULL;
+    if (M <= 0 || E <= 0) return HPCS_ERR_SHAPE;
+    hipLaunchKernelGGL(hyphc_finalize_kernel, dim3(1), dim3(64), 0, ST, loss_sum, kept, colsum, M, E, out);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
+extern "C" int hpcs_hyphc_grad_finalize(const float* g, const int64_t* kept, const double* colsum, const double* gscale_raw,
+                                        int64_t M, int E, float* gxn, float* gscale, hpcs_stream_t stream) {
+    if (!g || !kept || !colsum || !gxn) return HPCS_ERR_NULL;
+    if (gscale && !gscale_raw) return HPCS_ERR_NULL;
+    if (M <= 0 || E <= 0) return HPCS_ERR_SHAPE;
+    const int64_t total = M * E;
+    const unsigned blocks = (unsigned)(total / 1024 < 1 ? 1 : (total / 1024 > 4096 ? 4096 : total / 1024));
+    hipLaunchKernelGGL(hyphc_grad_finalize_kernel, dim3(blocks), dim3(256), 0, ST, g, kept, colsum, gscale_raw, M, E, gxn, gscale);
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;
 }

@@ -125,21 +125,23 @@ class HypHCSampledFn(torch.autograd.Function):
         _LAST_KEPT[0] = kept
         colsum = torch.empty(E, dtype=torch.float64, device=dev)
         call("hpcs_colsum", xn, M, E, colsum)
-        mean_sim = 0.5 + 0.5 * (colsum * colsum).sum() / float(M * M)
-        out = loss_sum[0] / kept[0].double() + mean_sim
+        out = torch.empty(1, dtype=torch.float32, device=dev)
+        call("hpcs_hyphc_finalize", loss_sum, kept, colsum, M, E, out)        # loss_sum / kept + 0.5 + 0.5 |colsum|^2 / M^2
         ctx.save_for_backward(scale, colsum, kept, gxn_raw, gscale_raw)
         ctx.M = M
-        return out.float()
+        return out[0]
 
     @staticmethod
     def backward(ctx, g):
         scale, colsum, kept, gxn_raw, gscale_raw = ctx.saved_tensors
         M = ctx.M
-        g32 = g.reshape(1).float()
-        inv = (g32.double() / kept.double().clamp_min(1)).float()
-        gxn = torch.addcmul((colsum / float(M * M)).float().mul(g32).unsqueeze(0), gxn_raw, inv)
-        gscale = (gscale_raw * inv.double()).float().view_as(scale)
-        return (gxn, gscale) + (None,) * 12
+        g32 = g.reshape(1)
+        if g32.dtype != torch.float32:
+            g32 = g32.float()
+        gscale = torch.empty(1, dtype=torch.float32, device=gxn_raw.device)
+        # in place on the kernel's unscaled gradient (a saved tensor nobody reads again): one launch
+        call("hpcs_hyphc_grad_finalize", g32, kept, colsum, gscale_raw, M, gxn_raw.shape[1], gxn_raw, gscale)
+        return (gxn_raw, gscale.view_as(scale)) + (None,) * 12
 
 
 class CosFaceFn(torch.autograd.Function):

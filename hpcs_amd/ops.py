@@ -750,7 +750,8 @@ class VNGraphLayerFn(torch.autograd.Function):
         gfeat = gWf = gWd = None
         W = Wp[:Ctot, :2 * C]                                            # [Wf;Wd] rows, (difference | centre) columns
         if ctx.needs_input_grad[0]:
-            Wuv = torch.cat([W[:, :C], W[:, C:] - W[:, :C]], 0).contiguous()          # [2Ctot, C]
+            Wuv = torch.empty(2 * Ctot, C, device=dev)                               # [Wa ; Wb - Wa]
+            call("hpcs_graph_wuv", Wp, Wp.shape[1], Ctot, C, Wuv)
             gfeat = gemm_WtG(Wuv, gUV, B, 2 * Ctot, 3 * N).view_as(feat)
         if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
             def weight_grads():
@@ -760,13 +761,11 @@ class VNGraphLayerFn(torch.autograd.Function):
             Wf_, Wd_ = ctx.wparams
             sink_f = _grad_sink((Wf_, ...)) if ctx.needs_input_grad[2] else None
             sink_d = _grad_sink((Wd_, ...)) if ctx.needs_input_grad[3] else None
-            if (sink_f is not None or not ctx.needs_input_grad[2]) and (sink_d is not None or not ctx.needs_input_grad[3]):
+            if (sink_f is not None or not ctx.needs_input_grad[2]) and (sink_d is not None or not ctx.needs_input_grad[3]) and \
+                    all(t is None or t.is_contiguous() for t in (sink_f, sink_d)):
                 def work():
-                    gWcat = weight_grads()
-                    if sink_f is not None:
-                        sink_f.add_(gWcat[:Cout])
-                    if sink_d is not None:
-                        sink_d.add_(gWcat[Cout:])
+                    gWuv = gemm_GXt(gUV, feat, B, 2 * Ctot, C, 3 * N)                # [2Ctot, C]
+                    call("hpcs_graph_wgrad_fold", gWuv, Ctot, C, Cout, sink_f, sink_d)    # [gU - gV | gV] added into .grad
                 _on_side_stream(work, (gUV, feat))
             else:
                 gWcat = weight_grads()

@@ -74,6 +74,12 @@ int hpcs_gemm_tn(const float* At, int lda, const float* Bm, int ldb, int64_t str
  * launch: At [K, lda >= M] = W^T and Wp [M, ldp >= K] = W, zero padded (lda, ldp multiples of 4 for 16-byte loads). */
 int hpcs_prep_weights(const float* W1, int ld1, int M1, const float* W2, int ld2, int M2, int K, float* At, int lda,
                       float* Wp, int ldp, hpcs_stream_t stream);
+/* EdgeConv weights at point level (W [x_nbr - x_ctr; x_ctr] = Wa x_nbr + (Wb - Wa) x_ctr, vn_dgcnn_util.py:33-39 + vn_layers.py:48-77):
+ * graph_wuv: W [Ctot, 2C] (row stride ldw; difference | centre columns) -> Wuv [2Ctot, C] = [Wa ; Wb - Wa].
+ * graph_wgrad_fold: gWuv [2Ctot, C] -> dW = [gU - gV | gV] ADDED into gWf [Cout, 2C] (rows < Cout) and gWd [Ctot-Cout, 2C]
+ * (either may be NULL: those rows are skipped). */
+int hpcs_graph_wuv(const float* W, int ldw, int Ctot, int C, float* Wuv, hpcs_stream_t stream);
+int hpcs_graph_wgrad_fold(const float* gWuv, int Ctot, int C, int Cout, float* gWf, float* gWd, hpcs_stream_t stream);
 size_t hpcs_gemm_nt_workspace(int M, int Kx, int Nc, int n_outer, int n_inner);
 int hpcs_gemm_nt(const float* G, int ldg, int64_t strideG_o, int64_t strideG_i, const float* X, int ldx,
                  int64_t strideX_o, int64_t strideX_i, int M, int Kx, int Nc, int n_outer, int n_inner, float* dW,
@@ -306,6 +312,13 @@ int hpcs_hyphc_sampled(const float* xn, const int64_t* labels, const int32_t* or
                        int64_t* n_dbg, hpcs_stream_t stream);
 /* mean of the M x M similarity in closed form: 0.5 + 0.5*|sum_i xn_i|^2/M^2.  colsum [E] double. */
 int hpcs_colsum(const float* xn, int64_t rows, int E, double* colsum, hpcs_stream_t stream);
+/* scalar tails of the sampled HypHC term (hpcs/loss/ultrametric_loss.py:27-40 mean over triplets + the closed-form mean
+ * similarity): out[0] = loss_sum/kept + 0.5 + 0.5*|colsum|^2/M^2;  backward, in place on the unscaled gradient:
+ * gxn[i,:] = colsum/M^2 * g + gxn[i,:] * (g / max(kept,1)), gscale[0] = gscale_raw * (g / max(kept,1)) (gscale NULL: skipped). */
+int hpcs_hyphc_finalize(const double* loss_sum, const int64_t* kept, const double* colsum, int64_t M, int E, float* out,
+                        hpcs_stream_t stream);
+int hpcs_hyphc_grad_finalize(const float* g, const int64_t* kept, const double* colsum, const double* gscale_raw, int64_t M,
+                             int E, float* gxn, float* gscale, hpcs_stream_t stream);
 /* cosface: plain CosFace = one level of singleton branches (branch_id NULL, n_levels 1).  Hierarchical CosFace
  * (next row f2: hierarchical_loss + HierarchicalCosFaceLoss, hpcs/loss/hierarchical_cosface_loss.py:9-87):
  * branch_id [n_levels, C] int32 gives each class its branch per level; loss_row = sum_l -log(sum_{c in branch_l(y)} p_c).
