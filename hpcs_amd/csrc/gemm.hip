@@ -43,79 +43,6 @@ __device__ __forceinline__ float4 ld4_guard(const float* __restrict__ rowp, int 
     return v;
 }
 
-// Epilogue of one tile: accumulators -> C (+ row bias, optional accumulate).  Callers guarantee that no wave still reads the
-// operand tiles in `lds_raw` (the main loop ends with a barrier).
-template <int BM, int BN, int BK, int WM, int WN>
-__device__ __forceinline__ void tn_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* __restrict__ Cp, int ldc, int M, int Nc,
-                                            const float* __restrict__ bias, int accumulate, int m0, int n0, int vecC,
-                                            float* lds_raw) {
-    constexpr int NT = WM * WN * 64;
-    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int lr = lane & 31, lk = lane >> 5;
-    if (vecC) {
-        // Epilogue through a wave-private LDS patch: the MFMA result holds 4-row x 1-column slivers per lane, i.e. one
-        // dword store per register (two 128-byte row segments per wave instruction).  Transposed through LDS each lane
-        // owns 4 CONSECUTIVE columns instead and the tile leaves as 16-byte stores, eight 128-byte row segments per
-        // instruction -- the shape that streams at the HBM rate (the EdgeConv mixes write 330 MB per launch).
-        constexpr int PP = 36;                                   // patch pitch: 16-byte aligned rows, conflict-free
-        static_assert(2 * BK * (BM + BN) >= NT / 64 * 32 * PP, "patch does not fit");
-        float* patch = lds_raw + wave * (32 * PP);
-        // (the main loop ended with a barrier: nobody reads As / Bs any more)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int row0 = m0 + wm * (BM / WM) + i * 32, col0 = n0 + wn * (BN / WN) + j * 32;
-                if (row0 >= M || col0 >= Nc) continue;           // wave-uniform
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    patch[((r & 3) + 8 * (r >> 2) + 4 * lk) * PP + lr] = acc[i][j][r];
-                __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0); the patch is wave-private: no barrier
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int rr = it * 8 + (lane >> 3), c4 = (lane & 7) * 4;
-                    const int row = row0 + rr, col = col0 + c4;
-                    if (row < M && col < Nc) {
-                        float4 v = *reinterpret_cast<const float4*>(patch + rr * PP + c4);
-                        if (bias) { const float bb = bias[row]; v.x += bb; v.y += bb; v.z += bb; v.w += bb; }
-                        float* dst = Cp + (int64_t)row * ldc + col;
-                        if (col + 3 < Nc) {
-                            if (accumulate) {
-                                const float4 o = *reinterpret_cast<const float4*>(dst);
-                                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-                            }
-                            *reinterpret_cast<float4*>(dst) = v;
-                        } else {
-                            const float vv[4] = {v.x, v.y, v.z, v.w};
-                            for (int q = 0; q < 4 && col + q < Nc; ++q) dst[q] = accumulate ? dst[q] + vv[q] : vv[q];
-                        }
-                    }
-                }
-                __builtin_amdgcn_s_waitcnt(0xC07F);              // the reads are done before the next tile overwrites
-            }
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn * (BN / WN) + j * 32 + lr;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                if (row < M && col < Nc) {
-                    float v = acc[i][j][r];
-                    if (bias) v += bias[row];
-                    float* dst = Cp + (int64_t)row * ldc + col;
-                    if (accumulate) v += *dst;
-                    *dst = v;
-                }
-            }
-        }
-}
-
 // One output tile of C = At^T * B: BM x BN, WM x WN waves of (BM/WM) x (BN/WN) each, BK-deep K steps, double-buffered LDS.
 // FAST: both operands are 16-byte loadable everywhere (lda, ldb, Nc multiples of 4, aligned bases): the loader is
 // straight-line code -- clamped addresses instead of guards (a clamped column only feeds output rows / columns that are never
@@ -124,9 +51,9 @@ __device__ __forceinline__ void tn_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN 
 // branches: 509 -> 487 us on vn1's forward, 57 -> 48 us on conv6's).  Measured on top of it and NOT kept: a second K step
 // of prefetch distance (two register sets, 124 VGPRs, still four waves per SIMD): 484 vs 487 us.
 template <int BM, int BN, int BK, int WM, int WN, bool FAST>
-__device__ __forceinline__ void tn_mainloop(const float* __restrict__ At, int lda, const float* __restrict__ Bp, int ldb, int M,
-                                            int Nc, int K, int m0, int n0, int vecA, int vecB, float* lds_raw,
-                                            f32x16 (&acc)[BM / WM / 32][BN / WN / 32]) {
+__device__ __forceinline__ void tn_tile(const float* __restrict__ At, int lda, const float* __restrict__ Bp, int ldb,
+                                        float* __restrict__ Cp, int ldc, int M, int Nc, int K, const float* __restrict__ bias,
+                                        int accumulate, int m0, int n0, int vecA, int vecB, int vecC, float* lds_raw) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int A_V4 = BK * BM / 4, B_V4 = BK * BN / 4;                  // 16-byte pieces of one operand tile
@@ -138,6 +65,7 @@ __device__ __forceinline__ void tn_mainloop(const float* __restrict__ At, int ld
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
 
+    f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -235,17 +163,68 @@ __device__ __forceinline__ void tn_mainloop(const float* __restrict__ At, int ld
         __syncthreads();
     }
 
-}
-
-template <int BM, int BN, int BK, int WM, int WN, bool FAST>
-__device__ __forceinline__ void tn_tile(const float* __restrict__ At, int lda, const float* __restrict__ Bp, int ldb,
-                                        float* __restrict__ Cp, int ldc, int M, int Nc, int K, const float* __restrict__ bias,
-                                        int accumulate, int m0, int n0, int vecA, int vecB, int vecC, float* lds_raw) {
-    f32x16 acc[BM / WM / 32][BN / WN / 32];
-    tn_mainloop<BM, BN, BK, WM, WN, FAST>(At, lda, Bp, ldb, M, Nc, K, m0, n0, vecA, vecB, lds_raw, acc);
     TN_STAMP(2);
-    tn_epilogue<BM, BN, BK, WM, WN>(acc, Cp, ldc, M, Nc, bias, accumulate, m0, n0, vecC, lds_raw);
-    TN_STAMP(3);
+    if (vecC) {
+        // Epilogue through a wave-private LDS patch: the MFMA result holds 4-row x 1-column slivers per lane, i.e. one
+        // dword store per register (two 128-byte row segments per wave instruction).  Transposed through LDS each lane
+        // owns 4 CONSECUTIVE columns instead and the tile leaves as 16-byte stores, eight 128-byte row segments per
+        // instruction -- the shape that streams at the HBM rate (the EdgeConv mixes write 330 MB per launch).
+        constexpr int PP = 36;                                   // patch pitch: 16-byte aligned rows, conflict-free
+        static_assert(2 * BK * (BM + BN) >= NT / 64 * 32 * PP, "patch does not fit");
+        float* patch = lds_raw + wave * (32 * PP);
+        // (the main loop ended with a barrier: nobody reads As / Bs any more)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row0 = m0 + wm * (BM / WM) + i * 32, col0 = n0 + wn * (BN / WN) + j * 32;
+                if (row0 >= M || col0 >= Nc) continue;           // wave-uniform
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    patch[((r & 3) + 8 * (r >> 2) + 4 * lk) * PP + lr] = acc[i][j][r];
+                __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0); the patch is wave-private: no barrier
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int rr = it * 8 + (lane >> 3), c4 = (lane & 7) * 4;
+                    const int row = row0 + rr, col = col0 + c4;
+                    if (row < M && col < Nc) {
+                        float4 v = *reinterpret_cast<const float4*>(patch + rr * PP + c4);
+                        if (bias) { const float bb = bias[row]; v.x += bb; v.y += bb; v.z += bb; v.w += bb; }
+                        float* dst = Cp + (int64_t)row * ldc + col;
+                        if (col + 3 < Nc) {
+                            if (accumulate) {
+                                const float4 o = *reinterpret_cast<const float4*>(dst);
+                                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                            }
+                            *reinterpret_cast<float4*>(dst) = v;
+                        } else {
+                            const float vv[4] = {v.x, v.y, v.z, v.w};
+                            for (int q = 0; q < 4 && col + q < Nc; ++q) dst[q] = accumulate ? dst[q] + vv[q] : vv[q];
+                        }
+                    }
+                }
+                __builtin_amdgcn_s_waitcnt(0xC07F);              // the reads are done before the next tile overwrites
+            }
+        TN_STAMP(3);
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * (BN / WN) + j * 32 + lr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (row < M && col < Nc) {
+                    float v = acc[i][j][r];
+                    if (bias) v += bias[row];
+                    float* dst = Cp + (int64_t)row * ldc + col;
+                    if (accumulate) v += *dst;
+                    *dst = v;
+                }
+            }
+        }
 }
 
 // Measured and NOT kept: a last row tile of 64 / 96 rows with its four waves side by side (M = 341 / 682 leave 43 / 86 dead
@@ -273,77 +252,12 @@ __global__ __launch_bounds__(WM* WN * 64, 4) void gemm_tn_kernel(
     tn_tile<BM, BN, BK, WM, WN, FAST>(At, lda, Bp, ldb, Cp, ldc, M, Nc, K, bias, accumulate, m0, n0, vecA, vecB, vecC, lds_raw);
 }
 
-// EdgeConv channel mix with the Vector-Neuron batch-norm statistics in its epilogue.  C[b] = At^T B[b] over rows of 3L columns
-// (x | y | z planes of one channel): one workgroup computes the SAME 64 x 128 tile of all three planes (three passes of the
-// main loop, three accumulator sets), stores them, and -- for the first `stat_rows` rows, the feature channels -- adds
-// sum_l |p| and sum_l |p|^2 (|p| = sqrt(px^2 + py^2 + pz^2) + 1e-6, vn_layers.py:80-103) of its 128 positions into `sums`
-// [2 * stat_rows] doubles.  The separate statistics pass (one more read of the 330 MB pre-activation tensor per layer)
-// disappears.  Needs L % 128 == 0 (a tile never straddles two planes) and M <= 64.
-constexpr float TN_VN_EPS = 1e-6f;                      // = VN_EPS of vn_layers.hip
-template <bool FAST, int OCC>
-__global__ __launch_bounds__(256, OCC) void gemm_tn_xyz_kernel(
-    const float* __restrict__ At, int lda, const float* __restrict__ Bm, int64_t sB, float* __restrict__ C, int64_t sC, int M,
-    int64_t L, int K, int tilesL, unsigned total, int vecA, int vecB, int vecC, double* __restrict__ sums, int stat_rows) {
-    constexpr int BM = 64, BN = 128, BK = 16, WM = 1, WN = 4, TM = 2, TN = 1;
-    __shared__ __attribute__((aligned(16))) float lds_raw[2 * BK * (BM + BN)];
-    const unsigned logical = hpcs_xcd_remap(blockIdx.x, total);
-    const int colTile = logical % tilesL;
-    const int batch = logical / tilesL;
-    const float* Bp = Bm + (int64_t)batch * sB;
-    float* Cp = C + (int64_t)batch * sC;
-    const int n0 = colTile * BN;
-    const int ld = (int)(3 * L);
-    f32x16 acc[3][TM][TN];
-#pragma unroll
-    for (int comp = 0; comp < 3; ++comp)
-        tn_mainloop<BM, BN, BK, WM, WN, FAST>(At, lda, Bp, ld, M, ld, K, 0, n0 + comp * (int)L, vecA, vecB, lds_raw, acc[comp]);
-#pragma unroll
-    for (int comp = 0; comp < 3; ++comp)
-        tn_epilogue<BM, BN, BK, WM, WN>(acc[comp], Cp, ld, M, ld, nullptr, 0, 0, n0 + comp * (int)L, vecC, lds_raw);
-    if (!sums) return;
-    // norms of this wave's 64 x 32 block -> wave-private LDS patch (row-major) -> row sums -> across the four waves -> atomics
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lr = lane & 31, lk = lane >> 5;
-    constexpr int NP = 33;
-    float* patch = lds_raw + wave * (32 * NP);
-    float* part = lds_raw + 4 * (32 * NP);                  // [4 waves][32 rows][2]
-    static_assert(4 * 32 * NP + 4 * 32 * 2 <= 2 * BK * (BM + BN), "statistics scratch does not fit");
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        if (i * 32 >= stat_rows) break;                      // uniform: no feature channel in this 32-row block
-        __syncthreads();                                     // the previous use of `patch` / `part` (epilogue, i - 1) is over
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float a0 = acc[0][i][0][r], a1 = acc[1][i][0][r], a2 = acc[2][i][0][r];
-            patch[((r & 3) + 8 * (r >> 2) + 4 * lk) * NP + lr] = sqrtf(a0 * a0 + a1 * a1 + a2 * a2) + TN_VN_EPS;
-        }
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        const int rowl = lane >> 1, half = lane & 1;
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            const float n = patch[rowl * NP + half * 16 + c];
-            s1 += n;
-            s2 += n * n;
-        }
-        s1 += __shfl_xor(s1, 1);
-        s2 += __shfl_xor(s2, 1);
-        if (half == 0) {
-            part[(wave * 32 + rowl) * 2] = s1;
-            part[(wave * 32 + rowl) * 2 + 1] = s2;
-        }
-        __syncthreads();
-        if (tid < 64) {
-            const int row = tid >> 1, which = tid & 1, ch = i * 32 + row;
-            if (ch < stat_rows) {
-                double t = 0.0;
-#pragma unroll
-                for (int w = 0; w < 4; ++w) t += (double)part[(w * 32 + row) * 2 + which];
-                atomicAdd(sums + which * stat_rows + ch, t);
-            }
-        }
-    }
-}
+// Measured and NOT kept: the VN batch-norm statistics in this GEMM's epilogue for the EdgeConv layers (one workgroup computing
+// the same 64 x 128 tile of the x, y and z planes, |p| from the three accumulator sets): bit-identical product, 220 vs 254 us
+// against GEMM + statistics pass on cold data, but 185 vs 71 + 40 us inside the step (the statistics pass reads the
+// pre-activations from the infinity cache; three accumulator sets leave two workgroups per CU).  Splitting the tile body into
+// main-loop and epilogue functions for it also cost the 64-row kernel its 72-VGPR allocation (128, i.e. 4 instead of 6
+// workgroups per CU: 74 -> 98 us per launch in the step), so the body stays one function.
 
 // Measured and NOT kept: a persistent form (min(tiles, 3-4 per CU) workgroups walk the tile list in the same XCD-aware order,
 // the next tile's first K step requested before the current tile's epilogue): vn1 forward 505-516 vs 496 us, EdgeConv mix
@@ -917,33 +831,6 @@ extern "C" int hpcs_graph_wgrad_fold(const float* gWuv, int Ctot, int C, int Cou
     if (Ctot <= 0 || C <= 0 || Cout < 0 || Cout > Ctot) return HPCS_ERR_SHAPE;
     hipLaunchKernelGGL(graph_wgrad_fold_kernel, dim3(hpcs_cdiv(Ctot * 2 * C, 256)), dim3(256), 0, (hipStream_t)stream, gWuv, Ctot, C,
                        Cout, gWf, gWd);
-    HPCS_CHECK_LAUNCH();
-    return HPCS_OK;
-}
-
-extern "C" int hpcs_gemm_tn_vnstats(const float* At, int lda, const float* X, float* PD, int M, int64_t L, int K, int B, double* sums,
-                                    int stat_rows, hpcs_stream_t stream) {
-    if (!At || !X || !PD) return HPCS_ERR_NULL;
-    if (M <= 0 || M > 64 || L <= 0 || L % 128 != 0 || 3 * L > 0x7fffffffLL || K <= 0 || B < 0 || lda < M || lda % 4 != 0 ||
-        stat_rows < 0 || stat_rows > M || (stat_rows > 0 && !sums))
-        return HPCS_ERR_SHAPE;
-    if (!aligned16(At) || !aligned16(X) || !aligned16(PD)) return HPCS_ERR_UNSUPPORTED;
-    if (B == 0) return HPCS_OK;
-    // problems that hpcs_gemm_tn gives to its per-element kernel (fewer than 32 tiles) keep that kernel's result: not served
-    if ((3 * L / 128) * B < 32 && K <= 4096) return HPCS_ERR_UNSUPPORTED;
-    const int tilesL = (int)(L / 128);
-    const long total = (long)tilesL * B;
-    if (total > 0x7fffffffL) return HPCS_ERR_UNSUPPORTED;
-    static int occ = -1;                                      // A/B switch: HPCS_GEMM_XYZ_OCC=3 (35 spilled VGPRs) | 2 (default)
-    if (occ < 0) { const char* e = getenv("HPCS_GEMM_XYZ_OCC"); occ = e ? atoi(e) : 2; }
-    if (occ == 3)
-        hipLaunchKernelGGL((gemm_tn_xyz_kernel<true, 3>), dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, At, lda, X,
-                           (int64_t)K * 3 * L, PD, (int64_t)M * 3 * L, M, L, K, tilesL, (unsigned)total, 1, 1, 1,
-                           stat_rows > 0 ? sums : (double*)nullptr, stat_rows);
-    else
-        hipLaunchKernelGGL((gemm_tn_xyz_kernel<true, 2>), dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, At, lda, X,
-                           (int64_t)K * 3 * L, PD, (int64_t)M * 3 * L, M, L, K, tilesL, (unsigned)total, 1, 1, 1,
-                           stat_rows > 0 ? sums : (double*)nullptr, stat_rows);
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;
 }

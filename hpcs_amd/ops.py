@@ -104,24 +104,6 @@ def gemm_WX(W, X, nb, K, Nc, rowbias=None, out=None, accumulate=False):
     return out
 
 
-# hpcs_gemm_tn_vnstats (VN batch-norm statistics in the channel mix's epilogue) is OFF by default: alone, on cold data, it beats
-# GEMM + statistics pass (220 vs 254 us per EdgeConv layer); inside the step the pre-activations are still in the 256 MB
-# infinity cache when the statistics pass reads them (71 + 40 us), and the fused kernel's three accumulator sets leave two
-# workgroups per CU: 185 us (profiles/r02_kernel_stats_summary.md history in DESIGN.md).
-FUSED_VN_STATS = __import__("os").environ.get("HPCS_FUSED_STATS", "0") != "0"
-
-
-def gemm_WX_vnstats(W, X, nb, K, L, sums, stat_rows):
-    """PD [nb, M, 3, L] = W X [nb, K, 3, L] with the VN batch-norm statistics of the first `stat_rows` rows added into `sums`
-    by the GEMM's epilogue (hpcs_gemm_tn_vnstats); None when the geometry is not served (caller: plain GEMM + statistics)."""
-    W = _prep(W)
-    if not FUSED_VN_STATS or W.M > 64 or L % 128 or X.data_ptr() % 16 or ((3 * L // 128) * nb < 32 and K <= 4096):
-        return None                     # (the last clause: hpcs_gemm_tn's per-element kernel serves such small problems)
-    out = torch.empty(nb * W.M * 3 * L, device=X.device, dtype=torch.float32)
-    call("hpcs_gemm_tn_vnstats", W.At, W.At.shape[1], X, out, W.M, L, K, nb, sums, stat_rows)
-    return out
-
-
 def gemm_WtG(W, G, nb, M, Nc, out=None, accumulate=False):
     """out[b] (K x Nc) = W^T (K x M) @ G[b] (M x Nc)."""
     W = _prep(W)
@@ -460,7 +442,6 @@ class VNLayerFn(torch.autograd.Function):
         Ctot = Cout + Cd
         Cc = 0
         xcT = None
-        sums, fused_stats = None, False
         ctx.wversions = (Wf._version, None if Wd is None else Wd._version)
         ctx.mean_mode = isinstance(xconst, str)
         if ctx.mean_mode:
@@ -487,24 +468,16 @@ class VNLayerFn(torch.autograd.Function):
             PD = _gemm_inner3(WxP, x, B, Cin, L, bias)
         else:
             WxP = PreparedW(Wf, Wd_)
-            PD = None
-            if training and (flags & VN_BN):                      # statistics in the GEMM's epilogue where it is served
-                sums = _zeros64(2 * Cout, x.device)
-                PD = gemm_WX_vnstats(WxP, x, B, Cin, L, sums, Cout)
-                fused_stats = PD is not None
-            if PD is None:
-                PD = gemm_WX(WxP, x, B, Cin, 3 * L)
+            PD = gemm_WX(WxP, x, B, Cin, 3 * L)
         Wx = WxP.Wp
         dev = x.device
         mean = rstd = None
         if flags & VN_BN:
             mean = torch.empty(Cout, device=dev)
             rstd = torch.empty(Cout, device=dev)
-            if not training:
-                sums = None
-            elif not fused_stats:
-                if sums is None:
-                    sums = _zeros64(2 * Cout, dev)
+            sums = None
+            if training:
+                sums = _zeros64(2 * Cout, dev)
                 call("hpcs_vn_norm_stats", PD, B, Cout, Ctot, L, sums, 1)
             call("hpcs_bn_finalize", sums, Cout, B * L, BN_EPS, BN_MOMENTUM, rmean, rvar, mean, rstd, 1 if training else 0)
         if pool_k:
@@ -734,12 +707,10 @@ class VNGraphLayerFn(torch.autograd.Function):
             if training:
                 call("hpcs_vn_norm_stats_k2", E, WxP.Wp, ldw, B, Cout, Ctot, L, sums, 1)
         else:
-            PD = gemm_WX_vnstats(WxP, E, B, 2 * C, L, sums, Cout) if training else None
-            if PD is None:
-                PD = gemm_WX(WxP, E, B, 2 * C, 3 * L)
-                if training:
-                    call("hpcs_vn_norm_stats", PD, B, Cout, Ctot, L, sums, 1)
+            PD = gemm_WX(WxP, E, B, 2 * C, 3 * L)
             del E
+            if training:
+                call("hpcs_vn_norm_stats", PD, B, Cout, Ctot, L, sums, 1)
         call("hpcs_bn_finalize", sums, Cout, B * L, BN_EPS, BN_MOMENTUM, rmean, rvar, mean, rstd, 1 if training else 0)
         out = torch.empty((B, Cout, 3, N) if pool_k else (B, Cout, 3, N, k), device=dev)
         if k2:

@@ -70,14 +70,6 @@ int hpcs_edge_gather_bwd(const float* gout, const int64_t* idx, int B, int C, in
 int hpcs_gemm_tn(const float* At, int lda, const float* Bm, int ldb, int64_t strideB_o, int64_t strideB_i,
                  float* C, int ldc, int64_t strideC_o, int64_t strideC_i, int M, int Nc, int K, int n_outer,
                  int n_inner, const float* rowbias, int accumulate, hpcs_stream_t stream);
-/* gemm_tn_vnstats: an EdgeConv channel mix (vn_layers.py:48-77 map_to_feat / map_to_dir on [B, K, 3, L]) with the VNBatchNorm
- * statistics (vn_layers.py:80-103) in its epilogue: PD [B, M, 3, L] = At^T X [B, K, 3, L] (M <= 64, L % 128 == 0, lda % 4 == 0,
- * 16-byte aligned pointers; the same fma chain as hpcs_gemm_tn), and for the first stat_rows rows
- * sums[c] += sum_{b,l} |p|, sums[stat_rows + c] += sum |p|^2 with |p| = sqrt(px^2+py^2+pz^2) + 1e-6 (sums pre-zeroed by the
- * caller: what hpcs_vn_norm_stats would add).  stat_rows == 0: plain GEMM.  Status -2 (unsupported): unaligned pointers, or a
- * problem so small (fewer than 32 tiles of 128 x 128) that hpcs_gemm_tn serves it with its per-element kernel. */
-int hpcs_gemm_tn_vnstats(const float* At, int lda, const float* X, float* PD, int M, int64_t L, int K, int B, double* sums,
-                         int stat_rows, hpcs_stream_t stream);
 /* prep_weights: W = [W1 (M1 x K, row stride ld1); W2 (M2 x K, row stride ld2, optional)] -> both GEMM operands in one
  * launch: At [K, lda >= M] = W^T and Wp [M, ldp >= K] = W, zero padded (lda, ldp multiples of 4 for 16-byte loads). */
 int hpcs_prep_weights(const float* W1, int ld1, int M1, const float* W2, int ld2, int M2, int K, float* At, int lda,

@@ -117,31 +117,6 @@ def test_gemm_tn_inner_batch():
     torch.testing.assert_close(C.cpu().double(), want, rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("B,K,M,Cout,L", [(4, 42, 42, 21, 2560), (2, 2, 42, 21, 20480), (3, 128, 64, 64, 1280), (5, 42, 42, 0, 1024)])
-def test_gemm_tn_vnstats_equals_gemm_plus_statistics(B, K, M, Cout, L):
-    """The EdgeConv channel mix with the VN batch-norm statistics in its epilogue: the product is BIT-identical to
-    hpcs_gemm_tn's, the statistics are what hpcs_vn_norm_stats adds (checked against fp64)."""
-    W = det_uniform((M, K), 210 + M)
-    X = det_normalish((B, K, 3, L), 310 + K).to(dev)
-    lda = (M + 3) // 4 * 4
-    At = torch.zeros(K, lda, device=dev)
-    At[:, :M] = W.t().to(dev)
-    ref = torch.empty(B, M, 3, L, device=dev)
-    _lib.call("hpcs_gemm_tn", At, lda, X, 3 * L, K * 3 * L, 0, ref, 3 * L, M * 3 * L, 0, M, 3 * L, K, B, 1, None, 0)
-    out = torch.empty(B, M, 3, L, device=dev)
-    sums = torch.zeros(max(2 * Cout, 1), dtype=torch.float64, device=dev)
-    _lib.call("hpcs_gemm_tn_vnstats", At, lda, X, out, M, L, K, B, sums if Cout else None, Cout)
-    assert torch.equal(out, ref)
-    if Cout:
-        n = ref[:, :Cout].double().pow(2).sum(2).sqrt() + 1e-6
-        want = torch.cat([n.sum((0, 2)), (n * n).sum((0, 2))])
-        assert float(((sums - want) / want).abs().max()) < 5e-7
-    # not served: L not a multiple of 128, M > 64, and problems of fewer than 32 tiles (the per-element kernel's domain)
-    f = _lib._fn("hpcs_gemm_tn_vnstats")
-    assert f(At.data_ptr(), lda, X.data_ptr(), out.data_ptr(), M, L + 4, K, B, sums.data_ptr(), Cout, None) == -1
-    assert f(At.data_ptr(), lda, X.data_ptr(), out.data_ptr(), M, 128, K, 1, sums.data_ptr(), Cout, None) == -2
-
-
 @pytest.mark.parametrize("M,Kx,Nc,nb", [(42, 42, 5000, 3), (341, 63, 3 * 256, 2), (682, 682, 3 * 64, 2), (256, 1, 1, 6),
                                         (3, 170, 96, 4)])
 def test_gemm_nt(M, Kx, Nc, nb):
