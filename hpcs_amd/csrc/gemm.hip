@@ -672,6 +672,31 @@ __global__ void prep_weights_kernel(const float* __restrict__ W1, int ld1, int M
     }
 }
 
+__global__ void prep_weights_multi_kernel(const hpcs_prep_desc* __restrict__ desc) {
+    const hpcs_prep_desc d = desc[blockIdx.y];
+    const float* W1 = reinterpret_cast<const float*>(d.W1);
+    const float* W2 = reinterpret_cast<const float*>(d.W2);
+    float* At = reinterpret_cast<float*>(d.At);
+    float* Wp = reinterpret_cast<float*>(d.Wp);
+    const int M = d.M1 + d.M2;
+    const int64_t nA = (int64_t)d.K * d.lda, nP = (int64_t)M * d.ldp;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nA + nP; e += (int64_t)gridDim.x * blockDim.x) {
+        if (e < nA) {
+            const int k = (int)(e / d.lda), m = (int)(e % d.lda);
+            float v = 0.f;
+            if (m < d.M1) v = W1[(int64_t)m * d.ld1 + k];
+            else if (m < M) v = W2[(int64_t)(m - d.M1) * d.ld2 + k];
+            At[e] = v;
+        } else {
+            const int64_t q = e - nA;
+            const int m = (int)(q / d.ldp), k = (int)(q % d.ldp);
+            float v = 0.f;
+            if (k < d.K) v = m < d.M1 ? W1[(int64_t)m * d.ld1 + k] : W2[(int64_t)(m - d.M1) * d.ld2 + k];
+            Wp[q] = v;
+        }
+    }
+}
+
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
 
 // Point-level form of an EdgeConv layer's weights (VNGraphLayerFn.backward): W = [Wa | Wb] (difference | centre columns) ->
@@ -831,6 +856,15 @@ extern "C" int hpcs_graph_wgrad_fold(const float* gWuv, int Ctot, int C, int Cou
     if (Ctot <= 0 || C <= 0 || Cout < 0 || Cout > Ctot) return HPCS_ERR_SHAPE;
     hipLaunchKernelGGL(graph_wgrad_fold_kernel, dim3(hpcs_cdiv(Ctot * 2 * C, 256)), dim3(256), 0, (hipStream_t)stream, gWuv, Ctot, C,
                        Cout, gWf, gWd);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
+extern "C" int hpcs_prep_weights_multi(const hpcs_prep_desc* desc_dev, int n, hpcs_stream_t stream) {
+    if (!desc_dev) return HPCS_ERR_NULL;
+    if (n < 0 || n > 65535) return HPCS_ERR_SHAPE;
+    if (n == 0) return HPCS_OK;
+    hipLaunchKernelGGL(prep_weights_multi_kernel, dim3(64, (unsigned)n), dim3(256), 0, (hipStream_t)stream, desc_dev);
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;
 }

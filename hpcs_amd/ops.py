@@ -69,6 +69,57 @@ def _pad4(n):
 
 
 # ------------------------------------------------------------------------------------------------ raw GEMMs
+class PrepCache:
+    """Step-level batching of the weight re-layouts (one instance per HypHCStep).  Every PreparedW built while the cache is
+    active is recorded with persistent operand buffers; from the next step on ONE multi-tensor launch at the head of the
+    step refreshes all of them (`begin_step()`, valid until `end_step()` -- the optimiser then moves the weights) and
+    PreparedW(...) finds its operands ready: 16 small launches per step less.  Outside a step nothing is cached or reused."""
+
+    def __init__(self, parameters=()):
+        # only weights that live inside a parameter's storage are recorded (a temporary operand has a new address every step)
+        self.ranges = sorted((p.data_ptr(), p.data_ptr() + p.numel() * p.element_size()) for p in parameters)
+        self.starts = [r[0] for r in self.ranges]
+        self.fresh = False
+        self.entries = {}          # key -> (At, Wp)
+        self.order = []            # keys in table order
+        self.table_dev = None
+        self.dirty = False         # entries were added since the table was built
+
+    def begin_step(self):
+        """Called by the step driver before the forward pass: refreshes every recorded operand pair in one launch."""
+        import struct
+        global _ACTIVE_PREP
+        _ACTIVE_PREP = self
+        self.fresh = False
+        if not self.order:
+            return
+        if self.dirty or self.table_dev is None:
+            if torch.cuda.is_current_stream_capturing():
+                return                                   # (no host->device copy inside a capture: per-layer launches this once)
+            blob = bytearray()
+            for key in self.order:
+                At, Wp = self.entries[key]
+                p1, ld1, M1, p2, ld2, M2, K = key
+                blob += struct.pack("<4Q8i", p1, p2, At.data_ptr(), Wp.data_ptr(), ld1, M1, ld2, M2, K, At.shape[1], Wp.shape[1], 0)
+            self.table_dev = torch.frombuffer(blob, dtype=torch.uint8).clone().to(self.entries[self.order[0]][0].device)
+            self.dirty = False
+        call("hpcs_prep_weights_multi", self.table_dev, len(self.order))
+        self.fresh = True
+
+    def owns(self, ptr):
+        import bisect
+        i = bisect.bisect_right(self.starts, ptr) - 1
+        return i >= 0 and ptr < self.ranges[i][1]
+
+    def end_step(self):
+        global _ACTIVE_PREP
+        self.fresh = False
+        _ACTIVE_PREP = None
+
+
+_ACTIVE_PREP = None
+
+
 class PreparedW:
     """GEMM operands of W = [W1; W2] built by ONE kernel: At = W^T [K, pad4(M)] and Wp = W [M, pad4(K)]."""
     __slots__ = ("At", "Wp", "M", "K")
@@ -83,10 +134,24 @@ class PreparedW:
         M2 = 0 if W2 is None else W2.shape[0]
         M = M1 + M2
         self.M, self.K = M, K
+        c = _ACTIVE_PREP
+        key = None
+        if c is not None and (W2 is None or W2.dtype == torch.float32) and c.owns(W1.data_ptr()) and \
+                (W2 is None or c.owns(W2.data_ptr())):
+            key = (W1.data_ptr(), W1.stride(0), M1, 0 if W2 is None else W2.data_ptr(), 0 if W2 is None else W2.stride(0), M2, K)
+            hit = c.entries.get(key) if c.fresh else None
+            if hit is not None:
+                self.At, self.Wp = hit                            # refreshed by this step's multi-tensor launch
+                return
         self.At = torch.empty(K, _pad4(M), device=W1.device, dtype=torch.float32)
         self.Wp = torch.empty(M, _pad4(K), device=W1.device, dtype=torch.float32)
         call("hpcs_prep_weights", W1.data_ptr(), W1.stride(0), M1, None if W2 is None else W2.data_ptr(),
              0 if W2 is None else W2.stride(0), M2, K, self.At, self.At.shape[1], self.Wp, self.Wp.shape[1])
+        if key is not None and key not in c.entries and not torch.cuda.is_current_stream_capturing():
+            # (buffers allocated during a capture live in the graph's private pool: never adopted as persistent ones)
+            c.entries[key] = (self.At, self.Wp)
+            c.order.append(key)
+            c.dirty = True
 
 
 def _prep(W):

@@ -11,7 +11,7 @@ import torch
 
 from .dp import FlatGradBucket
 from .loss.ultrametric_loss import HierarchicalMetricHyperbolicLoss, MetricHyperbolicLoss
-from .ops import deferred_weight_grads, zero_arena_release, zero_arena_reset
+from .ops import PrepCache, deferred_weight_grads, zero_arena_release, zero_arena_reset
 from .optim import RAdam
 
 
@@ -91,6 +91,7 @@ class HypHCStep(torch.nn.Module):
         self.graph_auto = mode == "auto"
         self.graph_warmup = 3               # eager steps before the capture (allocator pools, lazily built tables)
         self._graph = None
+        self._prep_cache = PrepCache()                 # rebuilt in configure() once the parameters are on the device
         self._eager_steps = 0
         self._tune = None                   # auto mode: {"phase", "t": {"eager": [...], "graph": [...]}, "ev"}
         self.metrics = True
@@ -113,6 +114,7 @@ class HypHCStep(torch.nn.Module):
         tables = self.optimizer.build_tables()            # only to size the block: undo its step-count advance
         group["step"] = step0
         self.params_block = StepParams(params[0].device, self.num_class, [t[1].numel() for t in tables])
+        self._prep_cache = PrepCache(params)
         return self
 
     def _next_rot_seed(self):
@@ -230,14 +232,18 @@ class HypHCStep(torch.nn.Module):
         """zero grads -> forward -> losses -> backward (weight gradients on the side stream, joined at the end)."""
         self.bucket.zero()
         zero_arena_reset(points.device)        # one memset for all the step's fp64 accumulators
-        losses = self.forward_losses(points, label, targets, rot=rot, drop_masks=drop_masks, ctx=ctx)
-        total = losses["loss_metric"] + losses["loss_hyp"]
-        if self.side_stream_wgrad:             # dW GEMMs on a side stream, joined before the all-reduce
-            with deferred_weight_grads():
+        self._prep_cache.begin_step()          # one launch re-lays out every layer's weights (recorded in the first step)
+        try:
+            losses = self.forward_losses(points, label, targets, rot=rot, drop_masks=drop_masks, ctx=ctx)
+            total = losses["loss_metric"] + losses["loss_hyp"]
+            if self.side_stream_wgrad:         # dW GEMMs on a side stream, joined before the all-reduce
+                with deferred_weight_grads():
+                    total.backward()
+            else:
                 total.backward()
-        else:
-            total.backward()
-        zero_arena_release()
+        finally:
+            self._prep_cache.end_step()        # the optimiser moves the weights next: nothing prepared stays valid
+            zero_arena_release()
         losses["total_loss"] = total
         # detached: a loss tensor that outlives the step keeps its autograd graph -- and the AccumulateGrad nodes of every
         # parameter, bound to the stream they were created on -- alive, which breaks a later stream capture

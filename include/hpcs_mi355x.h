@@ -80,6 +80,13 @@ int hpcs_prep_weights(const float* W1, int ld1, int M1, const float* W2, int ld2
  * (either may be NULL: those rows are skipped). */
 int hpcs_graph_wuv(const float* W, int ldw, int Ctot, int C, float* Wuv, hpcs_stream_t stream);
 int hpcs_graph_wgrad_fold(const float* gWuv, int Ctot, int C, int Cout, float* gWf, float* gWd, hpcs_stream_t stream);
+/* prep_weights_multi: the same for n weight matrices in ONE launch (a training step re-lays out every layer's weights once,
+ * after the optimiser moved them): desc_dev[n] on the device, pointers as 64-bit integers. */
+typedef struct {
+    uint64_t W1, W2, At, Wp;      /* W2 = 0: no second block */
+    int32_t ld1, M1, ld2, M2, K, lda, ldp, pad_;
+} hpcs_prep_desc;
+int hpcs_prep_weights_multi(const hpcs_prep_desc* desc_dev, int n, hpcs_stream_t stream);
 size_t hpcs_gemm_nt_workspace(int M, int Kx, int Nc, int n_outer, int n_inner);
 int hpcs_gemm_nt(const float* G, int ldg, int64_t strideG_o, int64_t strideG_i, const float* X, int ldx,
                  int64_t strideX_o, int64_t strideX_i, int M, int Kx, int Nc, int n_outer, int n_inner, float* dW,

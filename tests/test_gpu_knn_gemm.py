@@ -33,10 +33,12 @@ def test_knn_bit_exact(B, D, N, k, seed):
     assert torch.equal(got, want)
 
 
-@pytest.mark.parametrize("kernel", ["tiled", "insert", "queue"])
+@pytest.mark.parametrize("kernel", ["tiled", "insert", "queue", "bq"])
 def test_knn_both_mfma_kernels_bit_exact(kernel, monkeypatch):
-    """The two MFMA selection kernels (interleaved 4-wave tiles / one wave with per-lane queues) are chosen by problem
-    size; both must reproduce the oracle on every shape, duplicates included."""
+    """The MFMA selection kernels (interleaved 4-wave tiles with a sorting network or per-score insertion / one wave with
+    per-lane queues / one wave with a stack of pending candidates merged 16 at a time) are chosen by problem size and k;
+    each must reproduce the oracle on every shape, duplicates included ("bq" serves k <= 32: larger k falls through to the
+    queued kernel)."""
     monkeypatch.setenv("HPCS_KNN_KERNEL", kernel)
     for B, D, N, k, seed in [(2, 3, 256, 10, 31), (3, 3, 1024, 20, 32), (2, 63, 512, 20, 33), (1, 63, 2048, 40, 34),
                              (2, 3, 100, 7, 35), (1, 3, 64, 33, 36)]:
@@ -44,6 +46,20 @@ def test_knn_both_mfma_kernels_bit_exact(kernel, monkeypatch):
         assert torch.equal(hip_knn(x, k), OE.knn_exact(x, k)), (kernel, B, D, N, k)
     x = det_cloud(2, 128, 37, dup_every=5)
     assert torch.equal(hip_knn(x, 8), OE.knn_exact(x, 8))
+    # ties everywhere (a lattice: many equal distances), k = 1 / 4 / 32, a ragged last tile and a query tile beyond N
+    g = torch.arange(5, dtype=torch.float32)
+    lat = torch.stack(torch.meshgrid(g, g, g, indexing="ij")).reshape(1, 3, 125)
+    for k_ in (1, 4, 32):
+        assert torch.equal(hip_knn(lat, k_), OE.knn_exact(lat, k_)), (kernel, "lattice", k_)
+    x = det_cloud(3, 45, 38)
+    assert torch.equal(hip_knn(x, 16), OE.knn_exact(x, 16))
+
+
+def test_knn_batch_queue_kernel_is_the_default_for_many_queries():
+    """B * N / 32 >= 1024 query tiles and k <= 32 select the batch-queue kernel without any switch: same indices as the
+    oracle (and so as the sorting-network kernel, which the small shapes above take)."""
+    x = det_cloud(36, 1024, 39)
+    assert torch.equal(hip_knn(x, 20), OE.knn_exact(x, 20))
 
 
 @pytest.mark.parametrize("D", [3, 63])
