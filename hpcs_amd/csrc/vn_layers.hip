@@ -294,8 +294,65 @@ __device__ __forceinline__ void pd_load3(const PdRef& r, int64_t b, int ch, int6
     for (int a = 0; a < 3; ++a) v[a] = U[(int64_t)a * r.N + j] + V[(int64_t)a * r.N + n];
 }
 
+// BatchNorm finalisation inside the statistics kernels (training mode): the LAST workgroup to finish -- a ticket counter next to
+// the sums, zeroed with them -- turns the sums into mean / rstd and updates the running statistics, the arithmetic of
+// bn_finalize_kernel below.  One launch per normalisation layer less (13 per training step).
+struct BnFin {
+    unsigned* counter;          // [C] tickets, zeroed (nullptr: no finalisation, the caller launches hpcs_bn_finalize)
+    double count;
+    float eps, momentum;
+    float *rmean, *rvar, *mean, *rstd;
+};
+__device__ __forceinline__ void bn_finalize_channel(const double s1, const double s2, int c, double count, float eps, float momentum,
+                                                    float* rmean, float* rvar, float* mean, float* rstd) {
+    const double m = s1 / count;
+    double var = s2 / count - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)m;
+    rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (rmean) rmean[c] = (float)((1.0 - momentum) * rmean[c] + momentum * m);
+    if (rvar) {
+        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+        rvar[c] = (float)((1.0 - momentum) * rvar[c] + momentum * unb);
+    }
+}
+// Call from every thread of every workgroup AFTER the workgroup's atomic adds into `sums` (whichever threads issued them).
+// No __threadfence(): at agent scope it writes back and invalidates the XCD's L2 -- issued by thousands of workgroups it took
+// the whole step from 10.9 to 17 ms.  Nothing but device-scope atomics is published here (performed at the coherence point,
+// acknowledged through vmcnt), and the finalising workgroup reads the sums back with atomics; its own plain stores
+// (mean / rstd / running statistics) are consumed by later kernels only.
+__device__ __forceinline__ void bn_finalize_tail(const BnFin& f, double* sums, int C) {
+    if (f.counter == nullptr) return;
+    __shared__ int last_sh;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this thread's atomic adds have been performed
+    __syncthreads();                                          // ... and every other thread's of the workgroup
+    if (threadIdx.x == 0) {
+        const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+        last_sh = __hip_atomic_fetch_add(f.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == total - 1u;
+    }
+    __syncthreads();
+    if (!last_sh) return;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const double s1 = atomicAdd(sums + c, 0.0);           // read through the same path the adds took
+        const double s2 = atomicAdd(sums + C + c, 0.0);
+        bn_finalize_channel(s1, s2, c, f.count, f.eps, f.momentum, f.rmean, f.rvar, f.mean, f.rstd);
+    }
+}
+
+// Per-channel form for the kernels whose workgroups each serve ONE channel (a single ticket counter for ~7000 workgroups
+// serialises: 39 -> 110 us per statistics kernel): fin.counter[c] counts the workgroups of channel c, the last of them
+// finalises that channel.  Only the thread that issued the workgroup's atomics calls this.
+__device__ __forceinline__ void bn_finalize_tail_channel(const BnFin& f, double* sums, int C, int c, unsigned blocks_of_channel) {
+    if (f.counter == nullptr) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this thread's adds into sums[c], sums[C + c] are performed
+    if (__hip_atomic_fetch_add(f.counter + c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != blocks_of_channel - 1u) return;
+    const double s1 = atomicAdd(sums + c, 0.0);               // read through the same path the adds took
+    const double s2 = atomicAdd(sums + C + c, 0.0);
+    bn_finalize_channel(s1, s2, c, f.count, f.eps, f.momentum, f.rmean, f.rvar, f.mean, f.rstd);
+}
+
 __global__ void vn_norm_stats_kernel(PdRef pd, int B, int Ctot, int64_t L, int Cout,
-                                     double* __restrict__ sums) {
+                                     double* __restrict__ sums, BnFin fin) {
     __shared__ double red[16];
     const int c = blockIdx.y;
     const int64_t total = (int64_t)B * L;
@@ -318,6 +375,7 @@ __global__ void vn_norm_stats_kernel(PdRef pd, int B, int Ctot, int64_t L, int C
     if (threadIdx.x == 0) {
         atomicAdd(sums + c, r1);
         atomicAdd(sums + Cout + c, r2);
+        bn_finalize_tail_channel(fin, sums, Cout, c, gridDim.x);
     }
 }
 
@@ -337,7 +395,8 @@ __device__ __forceinline__ void k2_vec(const float* __restrict__ E, int64_t b, i
 }
 template <bool K2>
 __global__ __launch_bounds__(TPB) void vn_norm_stats_vec_kernel(const float* __restrict__ PD, int Ctot, int64_t L, int Cout,
-                                                               double* __restrict__ sums, const float* __restrict__ w2, int ldw) {
+                                                               double* __restrict__ sums, const float* __restrict__ w2, int ldw,
+                                                               BnFin fin) {
     __shared__ double red[16];
     const int c = blockIdx.y, b = blockIdx.z;
     const float* base = PD + (((int64_t)b * Ctot + c) * 3) * L;
@@ -373,6 +432,7 @@ __global__ __launch_bounds__(TPB) void vn_norm_stats_vec_kernel(const float* __r
     if (threadIdx.x == 0) {
         atomicAdd(sums + c, r1);
         atomicAdd(sums + Cout + c, r2);
+        bn_finalize_tail_channel(fin, sums, Cout, c, gridDim.x * gridDim.z);
     }
 }
 
@@ -382,16 +442,7 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, int C, doubl
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     if (training) {
-        const double m = sums[c] / count;
-        double var = sums[C + c] / count - m * m;
-        if (var < 0.0) var = 0.0;
-        mean[c] = (float)m;
-        rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-        if (rmean) rmean[c] = (float)((1.0 - momentum) * rmean[c] + momentum * m);
-        if (rvar) {
-            const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-            rvar[c] = (float)((1.0 - momentum) * rvar[c] + momentum * unb);
-        }
+        bn_finalize_channel(sums[c], sums[C + c], c, count, eps, momentum, rmean, rvar, mean, rstd);
     } else {
         mean[c] = rmean[c];
         rstd[c] = 1.0f / sqrtf(rvar[c] + eps);
@@ -719,7 +770,7 @@ __device__ __forceinline__ void k2_block_reduce(float (&s1)[COUT], float (&s2)[C
 
 template <int COUT>
 __global__ __launch_bounds__(TPB) void vn_norm_stats_k2all_kernel(const float* __restrict__ E, const float* __restrict__ w2, int ldw,
-                                                                 int64_t L, double* __restrict__ sums) {
+                                                                 int64_t L, double* __restrict__ sums, BnFin fin) {
     const int b = blockIdx.y;
     const int64_t l = ((int64_t)blockIdx.x * TPB + threadIdx.x) * 4;
     float s1[COUT], s2[COUT];
@@ -752,6 +803,7 @@ __global__ __launch_bounds__(TPB) void vn_norm_stats_k2all_kernel(const float* _
         }
     }
     k2_block_reduce<COUT>(s1, s2, sums, COUT);
+    bn_finalize_tail(fin, sums, COUT);
 }
 
 // The backward reduction walks the channels in a ROLLED loop (its body -- forward point, leaky-ReLU and norm backward of four
@@ -1178,7 +1230,7 @@ __global__ __launch_bounds__(1024) void partials_reduce_kernel(const float* __re
 }
 
 // ------------------------------------------------------------------------------ Conv1d heads: BN1d + act + mask
-__global__ void bn_stats_kernel(const float* __restrict__ Y, int B, int C, int64_t L, double* __restrict__ sums) {
+__global__ void bn_stats_kernel(const float* __restrict__ Y, int B, int C, int64_t L, double* __restrict__ sums, BnFin fin) {
     __shared__ double red[16];
     const int c = blockIdx.y;
     const int64_t total = (int64_t)B * L;
@@ -1198,6 +1250,7 @@ __global__ void bn_stats_kernel(const float* __restrict__ Y, int B, int C, int64
     if (threadIdx.x == 0) {
         atomicAdd(sums + c, r1);
         atomicAdd(sums + C + c, r2);
+        bn_finalize_tail_channel(fin, sums, C, c, gridDim.x);
     }
 }
 
@@ -2132,22 +2185,36 @@ extern "C" int hpcs_edge_gather_bwd(const float* gout, const int64_t* idx, int B
     return HPCS_OK;
 }
 
-static int vn_norm_stats_impl(PdRef pd, int B, int Cout, double* sums, int zeroed, hipStream_t st) {
+static BnFin bn_fin(unsigned* counter, int64_t count, float eps, float momentum, float* rmean, float* rvar, float* mean, float* rstd) {
+    BnFin f;
+    f.counter = counter;
+    f.count = (double)count;
+    f.eps = eps;
+    f.momentum = momentum;
+    f.rmean = rmean;
+    f.rvar = rvar;
+    f.mean = mean;
+    f.rstd = rstd;
+    return f;
+}
+static const BnFin NO_FIN = bn_fin(nullptr, 1, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr);
+
+static int vn_norm_stats_impl(PdRef pd, int B, int Cout, double* sums, int zeroed, hipStream_t st, BnFin fin = NO_FIN) {
     if (!zeroed && hipMemsetAsync(sums, 0, sizeof(double) * 2 * Cout, st) != hipSuccess) return HPCS_ERR_HIP;
     if (B == 0) return HPCS_OK;
     const bool vec_ok = pd.idx == nullptr && pd.L % 4 == 0 && (((uintptr_t)pd.base & 15u) == 0) && B <= 65535 && Cout <= 65535;
     if (vec_ok && pd.w2 == nullptr)
         hipLaunchKernelGGL(vn_norm_stats_vec_kernel<false>, dim3(hpcs_cdiv(pd.L, TPB * 4 * VEC_ITEMS), Cout, B), dim3(TPB), 0, st,
-                           pd.base, pd.Ctot, pd.L, Cout, sums, (const float*)nullptr, 0);
+                           pd.base, pd.Ctot, pd.L, Cout, sums, (const float*)nullptr, 0, fin);
     else if (vec_ok && Cout == 21 && pd.Ctot == 42)
         hipLaunchKernelGGL(vn_norm_stats_k2all_kernel<21>, dim3(hpcs_cdiv(pd.L, TPB * 4), B), dim3(TPB), 0, st, pd.base, pd.w2,
-                           pd.ldw, pd.L, sums);
+                           pd.ldw, pd.L, sums, fin);
     else if (vec_ok)
         hipLaunchKernelGGL(vn_norm_stats_vec_kernel<true>, dim3(hpcs_cdiv(pd.L, TPB * 4 * VEC_ITEMS), Cout, B), dim3(TPB), 0, st,
-                           pd.base, pd.Ctot, pd.L, Cout, sums, pd.w2, pd.ldw);
+                           pd.base, pd.Ctot, pd.L, Cout, sums, pd.w2, pd.ldw, fin);
     else
         hipLaunchKernelGGL(vn_norm_stats_kernel, dim3(hpcs_cdiv((int64_t)B * pd.L, TPB * ITEMS), Cout), dim3(TPB), 0, st, pd, B,
-                           pd.Ctot, pd.L, Cout, sums);
+                           pd.Ctot, pd.L, Cout, sums, fin);
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;
 }
@@ -2527,7 +2594,7 @@ extern "C" int hpcs_bn_stats(const float* Y, int B, int C, int64_t L, double* su
     if (bad_dims(B, C, L) || C > 65535) return HPCS_ERR_SHAPE;
     if (!sums_zeroed && hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, ST) != hipSuccess) return HPCS_ERR_HIP;
     if (B == 0) return HPCS_OK;
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(hpcs_cdiv((int64_t)B * L, TPB * ITEMS), C), dim3(TPB), 0, ST, Y, B, C, L, sums);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(hpcs_cdiv((int64_t)B * L, TPB * ITEMS), C), dim3(TPB), 0, ST, Y, B, C, L, sums, NO_FIN);
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;
 }
@@ -2713,6 +2780,52 @@ extern "C" int hpcs_scale_inplace(float* x, int64_t n, float s, hpcs_stream_t st
     if (n < 0) return HPCS_ERR_SHAPE;
     if (n == 0) return HPCS_OK;
     hipLaunchKernelGGL(scale_inplace_kernel, dim3(hpcs_cdiv(n, TPB)), dim3(TPB), 0, ST, x, n, s);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
+// ---- statistics + BatchNorm finalisation in ONE launch (training mode): the last workgroup finalises --------------------------
+static int fin_args_ok(const void* sums, const void* counter, const void* mean, const void* rstd, int64_t count) {
+    if (!sums || !counter || !mean || !rstd) return HPCS_ERR_NULL;
+    if (count <= 0) return HPCS_ERR_SHAPE;
+    return HPCS_OK;
+}
+
+extern "C" int hpcs_vn_norm_stats_finalize(const float* PD, int B, int Cout, int Ctot, int64_t L, double* sums, uint32_t* counter,
+                                           float eps, float momentum, float* running_mean, float* running_var, float* mean,
+                                           float* rstd, hpcs_stream_t stream) {
+    if (!PD) return HPCS_ERR_NULL;
+    int rc = fin_args_ok(sums, counter, mean, rstd, (int64_t)B * L);
+    if (rc) return rc;
+    if (bad_dims(B, Cout, L) || Ctot < Cout || Cout > 65535 || B == 0) return HPCS_ERR_SHAPE;
+    return vn_norm_stats_impl(PdRef{PD, nullptr, Ctot, L, 0, 0}, B, Cout, sums, 1, ST,
+                              bn_fin(counter, (int64_t)B * L, eps, momentum, running_mean, running_var, mean, rstd));
+}
+
+extern "C" int hpcs_vn_norm_stats_k2_finalize(const float* E, const float* W2, int ldw, int B, int Cout, int Ctot, int64_t L,
+                                              double* sums, uint32_t* counter, float eps, float momentum, float* running_mean,
+                                              float* running_var, float* mean, float* rstd, hpcs_stream_t stream) {
+    int rc = k2_args_ok(E, W2, ldw);
+    if (rc) return rc;
+    rc = fin_args_ok(sums, counter, mean, rstd, (int64_t)B * L);
+    if (rc) return rc;
+    if (bad_dims(B, Cout, L) || Ctot < Cout || B == 0) return HPCS_ERR_SHAPE;
+    PdRef pd{E, nullptr, Ctot, L, 0, 0};
+    pd.w2 = W2;
+    pd.ldw = ldw;
+    return vn_norm_stats_impl(pd, B, Cout, sums, 1, ST,
+                              bn_fin(counter, (int64_t)B * L, eps, momentum, running_mean, running_var, mean, rstd));
+}
+
+extern "C" int hpcs_bn_stats_finalize(const float* Y, int B, int C, int64_t L, double* sums, uint32_t* counter, float eps,
+                                      float momentum, float* running_mean, float* running_var, float* mean, float* rstd,
+                                      hpcs_stream_t stream) {
+    if (!Y) return HPCS_ERR_NULL;
+    int rc = fin_args_ok(sums, counter, mean, rstd, (int64_t)B * L);
+    if (rc) return rc;
+    if (bad_dims(B, C, L) || C > 65535 || B == 0) return HPCS_ERR_SHAPE;
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(hpcs_cdiv((int64_t)B * L, TPB * ITEMS), C), dim3(TPB), 0, ST, Y, B, C, L, sums,
+                       bn_fin(counter, (int64_t)B * L, eps, momentum, running_mean, running_var, mean, rstd));
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;
 }

@@ -64,6 +64,17 @@ def _zeros64(n, device):
     return torch.zeros(n, dtype=torch.float64, device=device)
 
 
+BN_FOLD = __import__("os").environ.get("HPCS_BN_FOLD", "1") != "0"     # A/B: 0 = statistics and finalisation as two launches
+
+
+def _zeros64_ticket(n, device):
+    """n = 2C zeroed doubles + C zeroed 32-bit ticket counters behind them (the statistics kernels' last workgroup of a
+    channel finalises it)."""
+    nt = (n // 2 + 1) // 2
+    buf = _zeros64(n + nt, device)
+    return buf[:n], buf[n:].view(torch.int32)
+
+
 def _pad4(n):
     return (n + 3) // 4 * 4
 
@@ -540,11 +551,15 @@ class VNLayerFn(torch.autograd.Function):
         if flags & VN_BN:
             mean = torch.empty(Cout, device=dev)
             rstd = torch.empty(Cout, device=dev)
-            sums = None
-            if training:
+            if training and not BN_FOLD:
                 sums = _zeros64(2 * Cout, dev)
                 call("hpcs_vn_norm_stats", PD, B, Cout, Ctot, L, sums, 1)
-            call("hpcs_bn_finalize", sums, Cout, B * L, BN_EPS, BN_MOMENTUM, rmean, rvar, mean, rstd, 1 if training else 0)
+                call("hpcs_bn_finalize", sums, Cout, B * L, BN_EPS, BN_MOMENTUM, rmean, rvar, mean, rstd, 1)
+            elif training:
+                sums, ticket = _zeros64_ticket(2 * Cout, dev)
+                call("hpcs_vn_norm_stats_finalize", PD, B, Cout, Ctot, L, sums, ticket, BN_EPS, BN_MOMENTUM, rmean, rvar, mean, rstd)
+            else:
+                call("hpcs_bn_finalize", None, Cout, B * L, BN_EPS, BN_MOMENTUM, rmean, rvar, mean, rstd, 0)
         if pool_k:
             out = torch.empty(B, Cout, 3, L // pool_k, device=dev)
         else:
@@ -763,20 +778,28 @@ class VNGraphLayerFn(torch.autograd.Function):
         flags = VN_BN | VN_LRELU
         mean = torch.empty(Cout, device=dev)
         rstd = torch.empty(Cout, device=dev)
-        sums = _zeros64(2 * Cout, dev) if training else None
+        sums, ticket = _zeros64_ticket(2 * Cout, dev) if training else (None, None)
         k2 = C == 1 and K2_ON_THE_FLY
         if k2:
             # two input channels (conv1): PD = W E is two fmas per value -- formed inside the point-wise kernels from the
             # 16 MB edge tensor, bit-identical to the GEMM's chain, instead of a 330 MB tensor written once and read 4 times
             PD, ldw = E, WxP.Wp.shape[1]
-            if training:
+            if training and not BN_FOLD:
                 call("hpcs_vn_norm_stats_k2", E, WxP.Wp, ldw, B, Cout, Ctot, L, sums, 1)
+                call("hpcs_bn_finalize", sums, Cout, B * L, BN_EPS, BN_MOMENTUM, rmean, rvar, mean, rstd, 1)
+            elif training:
+                call("hpcs_vn_norm_stats_k2_finalize", E, WxP.Wp, ldw, B, Cout, Ctot, L, sums, ticket, BN_EPS, BN_MOMENTUM, rmean,
+                     rvar, mean, rstd)
         else:
             PD = gemm_WX(WxP, E, B, 2 * C, 3 * L)
             del E
-            if training:
+            if training and not BN_FOLD:
                 call("hpcs_vn_norm_stats", PD, B, Cout, Ctot, L, sums, 1)
-        call("hpcs_bn_finalize", sums, Cout, B * L, BN_EPS, BN_MOMENTUM, rmean, rvar, mean, rstd, 1 if training else 0)
+                call("hpcs_bn_finalize", sums, Cout, B * L, BN_EPS, BN_MOMENTUM, rmean, rvar, mean, rstd, 1)
+            elif training:
+                call("hpcs_vn_norm_stats_finalize", PD, B, Cout, Ctot, L, sums, ticket, BN_EPS, BN_MOMENTUM, rmean, rvar, mean, rstd)
+        if not training:
+            call("hpcs_bn_finalize", None, Cout, B * L, BN_EPS, BN_MOMENTUM, rmean, rvar, mean, rstd, 0)
         out = torch.empty((B, Cout, 3, N) if pool_k else (B, Cout, 3, N, k), device=dev)
         if k2:
             call("hpcs_vn_apply_fwd_k2", PD, WxP.Wp, ldw, mean, rstd, gamma, beta, B, Cout, Cd, L, pool_k, slope, flags, out)
@@ -882,11 +905,15 @@ class BnActFn(torch.autograd.Function):
         dev = y.device
         mean = torch.empty(C, device=dev)
         rstd = torch.empty(C, device=dev)
-        sums = None
-        if training:
+        if training and not BN_FOLD:
             sums = _zeros64(2 * C, dev)
             call("hpcs_bn_stats", y, B, C, L, sums, 1)
-        call("hpcs_bn_finalize", sums, C, B * L, BN_EPS, BN_MOMENTUM, rmean, rvar, mean, rstd, 1 if training else 0)
+            call("hpcs_bn_finalize", sums, C, B * L, BN_EPS, BN_MOMENTUM, rmean, rvar, mean, rstd, 1)
+        elif training:                     # statistics + finalisation in one launch (the last workgroup finalises)
+            sums, ticket = _zeros64_ticket(2 * C, dev)
+            call("hpcs_bn_stats_finalize", y, B, C, L, sums, ticket, BN_EPS, BN_MOMENTUM, rmean, rvar, mean, rstd)
+        else:
+            call("hpcs_bn_finalize", None, C, B * L, BN_EPS, BN_MOMENTUM, rmean, rvar, mean, rstd, 0)
         out = torch.empty_like(y)
         call("hpcs_bn_act_fwd", y, mean, rstd, gamma, beta, mask, dseed, dsd, dp, B, C, L, slope, out)
         ctx.save_for_backward(y, mean, rstd, gamma, beta, mask)

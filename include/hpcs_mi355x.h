@@ -109,6 +109,17 @@ int hpcs_gemm_nt(const float* G, int ldg, int64_t strideG_o, int64_t strideG_i, 
 int hpcs_vn_norm_stats(const float* PD, int B, int Cout, int Ctot, int64_t L, double* sums, int sums_zeroed, hpcs_stream_t stream);
 int hpcs_bn_finalize(const double* sums, int C, int64_t count, float eps, float momentum, float* running_mean,
                      float* running_var, float* mean, float* rstd, int training, hpcs_stream_t stream);
+/* Statistics + finalisation in ONE launch (training mode): the last workgroup of the statistics kernel turns the sums into
+ * mean / rstd and updates the running statistics (what hpcs_bn_finalize does in a launch of its own).  `sums` [2C] doubles and
+ * `counter` [C] uint32 tickets (one per channel: the last workgroup OF A CHANNEL finalises it) must arrive zeroed. */
+int hpcs_vn_norm_stats_finalize(const float* PD, int B, int Cout, int Ctot, int64_t L, double* sums, uint32_t* counter, float eps,
+                                float momentum, float* running_mean, float* running_var, float* mean, float* rstd,
+                                hpcs_stream_t stream);
+int hpcs_vn_norm_stats_k2_finalize(const float* E, const float* W2, int ldw, int B, int Cout, int Ctot, int64_t L, double* sums,
+                                   uint32_t* counter, float eps, float momentum, float* running_mean, float* running_var,
+                                   float* mean, float* rstd, hpcs_stream_t stream);
+int hpcs_bn_stats_finalize(const float* Y, int B, int C, int64_t L, double* sums, uint32_t* counter, float eps, float momentum,
+                           float* running_mean, float* running_var, float* mean, float* rstd, hpcs_stream_t stream);
 int hpcs_vn_apply_fwd(const float* PD, const float* mean, const float* rstd, const float* gamma,
                       const float* beta, int B, int Cout, int Cd, int64_t L, int pool_k, float slope, int flags,
                       float* out, hpcs_stream_t stream);

@@ -152,6 +152,39 @@ def test_shared_direction_layer_vs_fp64_oracle(B, Cin, Cout, L):
         relclose(p_.grad, P["c." + n_].grad, 5e-5)
 
 
+@pytest.mark.parametrize("B,C,L", [(4, 21, 20480), (2, 341, 1024), (3, 7, 50), (1, 256, 4096)])
+def test_statistics_kernels_finalise_in_their_last_workgroup(B, C, L):
+    """hpcs_*_stats_finalize (statistics + BatchNorm finalisation in one launch: the last workgroup finalises) against the two
+    separate launches: mean, rstd and the running statistics agree (the sums are fp64 atomics in both: order-dependent only
+    in the last bits)."""
+    from hpcs_amd import _lib
+    call = _lib.call
+    for kind in ("vn", "bn"):
+        x = det_normalish((B, C, 3, L) if kind == "vn" else (B, C, L), 60 + C).to(dev)
+        rm0, rv0 = det_uniform((C,), 61).to(dev), (det_uniform((C,), 62).abs() + 0.5).to(dev)
+        res = []
+        for fused in (False, True):
+            rm, rv = rm0.clone(), rv0.clone()
+            mean, rstd = torch.empty(C, device=dev), torch.empty(C, device=dev)
+            buf = torch.zeros(2 * C + (C + 1) // 2, dtype=torch.float64, device=dev)
+            sums, ticket = buf[:2 * C], buf[2 * C:].view(torch.int32)
+            if kind == "vn" and not fused:
+                call("hpcs_vn_norm_stats", x, B, C, C, L, sums, 1)
+            elif kind == "bn" and not fused:
+                call("hpcs_bn_stats", x, B, C, L, sums, 1)
+            if not fused:
+                call("hpcs_bn_finalize", sums, C, B * L, 1e-5, 0.1, rm, rv, mean, rstd, 1)
+            elif kind == "vn":
+                call("hpcs_vn_norm_stats_finalize", x, B, C, C, L, sums, ticket, 1e-5, 0.1, rm, rv, mean, rstd)
+            else:
+                call("hpcs_bn_stats_finalize", x, B, C, L, sums, ticket, 1e-5, 0.1, rm, rv, mean, rstd)
+            res.append((mean, rstd, rm, rv))
+        for a, b in zip(*res):
+            torch.testing.assert_close(a, b, rtol=2e-6, atol=1e-7)
+        ref = (x.double().pow(2).sum(2).sqrt() + 1e-6) if kind == "vn" else x.double()
+        torch.testing.assert_close(res[1][0].double().cpu(), ref.mean((0, 2)).cpu(), rtol=1e-5, atol=1e-6)
+
+
 def test_fused_mean_pool_matches_unfused():
     from hpcs_amd.nn.dgcnn.utils.vn_layers import VNLinearLeakyReLU, mean_pool
     x5 = det_normalish((2, 6, 3, 16, 4), 30).to(dev)
