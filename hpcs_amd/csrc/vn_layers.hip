@@ -2109,7 +2109,7 @@ __global__ __launch_bounds__(INV_T) void edge_grad_reduce_slab_kernel(const floa
 // *slabs = 1: one graph per cloud (N <= 1024, N*k <= INV_MAXL); > 1: N*k is a multiple of INV_MAXL and every slab of
 // N / slabs source points owns exactly INV_MAXL edges (N <= 2048), allowed only when the caller handles slabs.
 bool inv_graph_build(const int64_t* idx, int B, int N, int k, bool vec, void* ws, size_t ws_bytes, hipStream_t st, InvGraph* out,
-                     int* slabs = nullptr) {
+                     int* slabs = nullptr, bool launch = true) {
     static const bool off = getenv("HPCS_EDGE_BWD_ATOMIC") != nullptr;
     const int64_t L = (int64_t)N * k;
     if (off || !vec || (L % 4) != 0) return false;
@@ -2122,7 +2122,8 @@ bool inv_graph_build(const int64_t* idx, int B, int N, int k, bool vec, void* ws
     const int Ls = (int)(L / S);
     const InvGraph g = inv_graph_layout(ws, B * S, N, Ls);
     if (ws_bytes < g.bytes) return false;
-    if (N <= INV_T)
+    if (!launch) {                                   // the tables were built earlier (hpcs_edge_graph_transpose)
+    } else if (N <= INV_T)
         hipLaunchKernelGGL((knn_inverse_kernel<1>), dim3(B * S), dim3(INV_T), 0, st, idx, N, Ls, S, g.in_ptr, g.in_edge, g.hub_cnt,
                            g.hub_ids, g.hub_slot);
     else
@@ -2528,9 +2529,9 @@ extern "C" size_t hpcs_edge_grad_reduce_workspace(int B, int Ctot, int N) {
 }
 
 // GPD [B,Ctot,3,N*k] -> gUV [B,2*Ctot,3,N]: gU = scatter-add over idx (row-contiguous atomics), gV = sum over k
-extern "C" int hpcs_edge_grad_reduce(const float* GPD, const int64_t* idx, int B, int Ctot, int N, int k, float* gUV,
-                                     void* ws, size_t ws_bytes, hpcs_stream_t stream) {
-    if (!GPD || !idx || !gUV || !ws) return HPCS_ERR_NULL;
+static int edge_grad_reduce_impl(const float* GPD, const int64_t* idx, int B, int Ctot, int N, int k, float* gUV, void* ws,
+                                 size_t ws_bytes, hpcs_stream_t stream, bool prebuilt) {
+    if (!GPD || (!idx && !prebuilt) || !gUV || !ws) return HPCS_ERR_NULL;
     if (B < 0 || Ctot <= 0 || N <= 0 || k <= 0 || Ctot > 65535 || B > 65535) return HPCS_ERR_SHAPE;
     if (B == 0) return HPCS_OK;
     if (ws_bytes < hpcs_edge_grad_reduce_workspace(B, Ctot, N)) return HPCS_ERR_WORKSPACE;
@@ -2540,7 +2541,7 @@ extern "C" int hpcs_edge_grad_reduce(const float* GPD, const int64_t* idx, int B
     {   // inverse-graph path (see edge_gather_bwd_inv_kernel): no atomics, no scratch memset, GPD read once
         InvGraph ig;
         int slabs = 1;
-        if (inv_graph_build(idx, B, N, k, vec, ws, ws_bytes, ST, &ig, &slabs)) {
+        if (inv_graph_build(idx, B, N, k, vec, ws, ws_bytes, ST, &ig, &slabs, !prebuilt)) {
             HPCS_CHECK_LAUNCH();
             if (slabs > 1) {
                 int groups = inv_groups(B, Ctot * 3);
@@ -2572,6 +2573,7 @@ extern "C" int hpcs_edge_grad_reduce(const float* GPD, const int64_t* idx, int B
             return HPCS_OK;
         }
     }
+    if (prebuilt) return HPCS_ERR_UNSUPPORTED;           // the transposed graph does not serve this call (alignment / geometry)
     if (vec)
         hipLaunchKernelGGL((edge_segsum_kernel<true>), dim3(hpcs_cdiv(N, 64), Ctot, B), dim3(64), 0, ST, GPD, Ctot, N, k, gUV);
     else
@@ -2587,6 +2589,31 @@ extern "C" int hpcs_edge_grad_reduce(const float* GPD, const int64_t* idx, int B
                        CP, 0, gUV);
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;
+}
+
+extern "C" int hpcs_edge_grad_reduce(const float* GPD, const int64_t* idx, int B, int Ctot, int N, int k, float* gUV,
+                                     void* ws, size_t ws_bytes, hpcs_stream_t stream) {
+    return edge_grad_reduce_impl(GPD, idx, B, Ctot, N, k, gUV, ws, ws_bytes, stream, false);
+}
+
+// The transposed graph depends on the kNN indices only: it can be built as soon as they exist (in the forward pass, on a side
+// stream) and handed to the backward pass in the workspace.
+extern "C" int hpcs_edge_graph_transpose(const int64_t* idx, int B, int Ctot, int N, int k, void* ws, size_t ws_bytes,
+                                         hpcs_stream_t stream) {
+    if (!idx || !ws) return HPCS_ERR_NULL;
+    if (B < 0 || Ctot <= 0 || N <= 0 || k <= 0 || Ctot > 65535 || B > 65535) return HPCS_ERR_SHAPE;
+    if (B == 0) return HPCS_OK;
+    if (ws_bytes < hpcs_edge_grad_reduce_workspace(B, Ctot, N)) return HPCS_ERR_WORKSPACE;
+    InvGraph ig;
+    int slabs = 1;
+    if (!inv_graph_build(idx, B, N, k, k % 4 == 0, ws, ws_bytes, ST, &ig, &slabs)) return HPCS_ERR_UNSUPPORTED;
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
+extern "C" int hpcs_edge_grad_reduce_prebuilt(const float* GPD, int B, int Ctot, int N, int k, float* gUV, void* ws, size_t ws_bytes,
+                                              hpcs_stream_t stream) {
+    return edge_grad_reduce_impl(GPD, nullptr, B, Ctot, N, k, gUV, ws, ws_bytes, stream, true);
 }
 
 extern "C" int hpcs_bn_stats(const float* Y, int B, int C, int64_t L, double* sums, int sums_zeroed, hpcs_stream_t stream) {

@@ -228,9 +228,26 @@ class _SideWGrad:
     the HBM-bound element-wise passes.  Outside the context (or for parameters without a pre-allocated `.grad`)
     dW is returned to autograd as usual."""
     enabled = False
+    forward = False
     stream = None
     used = False
     keep = []
+
+
+class forward_side_stream:
+    """Context manager (step driver): inside it the graph layers build their transposed kNN graph for the backward pass
+    already in the forward pass, on the side stream, where it overlaps the forward kernels (45 us per layer off the
+    backward's critical path).  Only where a backward pass is certain to follow: the side stream is joined there."""
+
+    def __enter__(self):
+        if _SideWGrad.stream is None:
+            _SideWGrad.stream = torch.cuda.Stream()
+        _SideWGrad.forward = True
+        return self
+
+    def __exit__(self, *exc):
+        _SideWGrad.forward = False
+        return False
 
 
 class deferred_weight_grads:
@@ -808,6 +825,18 @@ class VNGraphLayerFn(torch.autograd.Function):
         ctx.save_for_backward(feat, idx, WxP.Wp, PD, mean, rstd, gamma, beta)
         ctx.cfg = (B, C, N, k, Cout, Cd, pool_k, slope, flags, bool(training))
         ctx.k2 = k2
+        ctx.tgraph = None
+        if _SideWGrad.forward and graph_backward_supported(N, k) and any(ctx.needs_input_grad[i] for i in (0, 2, 3)):
+            # the transposed graph of the backward's gradient reduction depends on idx only: built now, on the side stream
+            nbytes = call("hpcs_edge_grad_reduce_workspace", B, Ctot, N)
+            ws = torch.empty(nbytes // 4, device=dev)
+            side = _SideWGrad.stream
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                call("hpcs_edge_graph_transpose", idx, B, Ctot, N, k, ws, nbytes)
+                ev = torch.cuda.Event()
+                ev.record()
+            ctx.tgraph = (ws, nbytes, ev)
         return out
 
     @staticmethod
@@ -831,9 +860,15 @@ class VNGraphLayerFn(torch.autograd.Function):
             call("hpcs_vn_bwd_apply", PD, g, mean, rstd, gamma, beta, red, 1 if training else 0, B, Cout, Cd, L, pool_k, slope,
                  flags, GPD, sg, sb)
         gUV = torch.empty(B, 2 * Ctot, 3, N, device=dev)
-        nbytes = call("hpcs_edge_grad_reduce_workspace", B, Ctot, N)
-        ws = torch.empty(nbytes // 4, device=dev)
-        call("hpcs_edge_grad_reduce", GPD, idx, B, Ctot, N, k, gUV, ws, nbytes)
+        if ctx.tgraph is not None:                                       # transposed graph built during the forward pass
+            ws, nbytes, ev = ctx.tgraph
+            torch.cuda.current_stream().wait_event(ev)
+            call("hpcs_edge_grad_reduce_prebuilt", GPD, B, Ctot, N, k, gUV, ws, nbytes)
+            ctx.tgraph = None
+        else:
+            nbytes = call("hpcs_edge_grad_reduce_workspace", B, Ctot, N)
+            ws = torch.empty(nbytes // 4, device=dev)
+            call("hpcs_edge_grad_reduce", GPD, idx, B, Ctot, N, k, gUV, ws, nbytes)
         del GPD
         gfeat = gWf = gWd = None
         W = Wp[:Ctot, :2 * C]                                            # [Wf;Wd] rows, (difference | centre) columns

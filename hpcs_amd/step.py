@@ -11,8 +11,10 @@ import torch
 
 from .dp import FlatGradBucket
 from .loss.ultrametric_loss import HierarchicalMetricHyperbolicLoss, MetricHyperbolicLoss
-from .ops import PrepCache, deferred_weight_grads, zero_arena_release, zero_arena_reset
+from .ops import PrepCache, deferred_weight_grads, forward_side_stream, zero_arena_release, zero_arena_reset
 from .optim import RAdam
+
+FORWARD_SIDE = __import__("os").environ.get("HPCS_FWD_SIDE", "1") != "0"      # A/B: graph transposes in the forward pass
 
 
 def random_rotations(B, device, generator=None):
@@ -234,7 +236,11 @@ class HypHCStep(torch.nn.Module):
         zero_arena_reset(points.device)        # one memset for all the step's fp64 accumulators
         self._prep_cache.begin_step()          # one launch re-lays out every layer's weights (recorded in the first step)
         try:
-            losses = self.forward_losses(points, label, targets, rot=rot, drop_masks=drop_masks, ctx=ctx)
+            if self.side_stream_wgrad and FORWARD_SIDE:          # the backward below is certain to follow and joins the stream
+                with forward_side_stream():
+                    losses = self.forward_losses(points, label, targets, rot=rot, drop_masks=drop_masks, ctx=ctx)
+            else:
+                losses = self.forward_losses(points, label, targets, rot=rot, drop_masks=drop_masks, ctx=ctx)
             total = losses["loss_metric"] + losses["loss_hyp"]
             if self.side_stream_wgrad:         # dW GEMMs on a side stream, joined before the all-reduce
                 with deferred_weight_grads():

@@ -188,6 +188,13 @@ int hpcs_vn_edge_bwd_apply(const float* UV, const int64_t* idx, const float* gou
 size_t hpcs_edge_grad_reduce_workspace(int B, int Ctot, int N);
 int hpcs_edge_grad_reduce(const float* GPD, const int64_t* idx, int B, int Ctot, int N, int k, float* gUV, void* ws,
                           size_t ws_bytes, hpcs_stream_t stream);
+/* The transposed graph depends on the kNN indices only: hpcs_edge_graph_transpose builds it into `ws` (same size query) as soon
+ * as idx exists -- e.g. during the forward pass on another stream -- and hpcs_edge_grad_reduce_prebuilt runs the reduction from
+ * it.  Both return -2 (unsupported) for geometries / alignments the transposed-graph kernels do not serve: use
+ * hpcs_edge_grad_reduce then. */
+int hpcs_edge_graph_transpose(const int64_t* idx, int B, int Ctot, int N, int k, void* ws, size_t ws_bytes, hpcs_stream_t stream);
+int hpcs_edge_grad_reduce_prebuilt(const float* GPD, int B, int Ctot, int N, int k, float* gUV, void* ws, size_t ws_bytes,
+                                   hpcs_stream_t stream);
 
 /* ---- Conv1d(k=1)+BatchNorm1d(+LeakyReLU)(+Dropout mask)  vn_dgcnn_partseg.py:40-57,97-102 ------
  * Y [B,C,L] is the Conv1d output (hpcs_gemm_tn).  slope = 1 means no activation; mask (nullable,

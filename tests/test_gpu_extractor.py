@@ -185,6 +185,34 @@ def test_statistics_kernels_finalise_in_their_last_workgroup(B, C, L):
         torch.testing.assert_close(res[1][0].double().cpu(), ref.mean((0, 2)).cpu(), rtol=1e-5, atol=1e-6)
 
 
+def test_graph_transposed_in_the_forward_pass_gives_the_same_gradients():
+    """Inside ops.forward_side_stream() a graph layer builds the transposed kNN graph of its backward reduction during the
+    forward pass on the side stream (hpcs_edge_graph_transpose + hpcs_edge_grad_reduce_prebuilt): same tables, so the
+    gradients are bit-identical to the build-in-backward path."""
+    from hpcs_amd import ops
+    from hpcs_amd.nn.dgcnn.utils.vn_layers import VNLinearLeakyReLU
+    B, C, N, k = 3, 21, 1024, 20
+    feat = det_normalish((B, C, 3, N), 830)
+    idx = det_int((B, N, k), 831, N).to(dev)
+    w = None
+    res = []
+    for early in (False, True):
+        m = load(VNLinearLeakyReLU(2 * C, 21), 832)
+        m.train()
+        fg = feat.to(dev).requires_grad_(True)
+        if early:
+            with ops.forward_side_stream():
+                y = m.forward_graph(fg, idx, pool_k=k)
+        else:
+            y = m.forward_graph(fg, idx, pool_k=k)
+        w = det_uniform(tuple(y.shape), 833).to(dev) if w is None else w
+        (y * w).sum().backward()
+        torch.cuda.synchronize()
+        res.append((y.detach(), fg.grad, m.map_to_feat.weight.grad, m.map_to_dir.weight.grad))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
 def test_fused_mean_pool_matches_unfused():
     from hpcs_amd.nn.dgcnn.utils.vn_layers import VNLinearLeakyReLU, mean_pool
     x5 = det_normalish((2, 6, 3, 16, 4), 30).to(dev)
