@@ -258,7 +258,7 @@ __global__ __launch_bounds__(MW * 64) void knn_mfma_kernel(const float* __restri
 // j < 2^20 (hpcs_knn sends larger clouds to the scalar kernel).
 __device__ __forceinline__ double knn_key(float s, int j) {
     const unsigned u = __float_as_uint(s + 0.0f);                      // -0 -> +0: equal scores must give equal high words
-    const unsigned hi = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    const unsigned hi = u ^ ((unsigned)((int)u >> 31) | 0x80000000u);  // negative: ~u, else u | sign bit (order-preserving)
     const unsigned lo20 = 0xFFFFFu - (unsigned)j;                      // j < 2^20
     return __hiloint2double((int)(0x43300000u | (hi >> 12)), (int)((hi << 20) | lo20));
 }
@@ -576,10 +576,15 @@ __global__ __launch_bounds__(64) void knn_mfma_bq_kernel(const float* __restrict
 #pragma unroll
     for (int m = 0; m < 32; ++m) lst[m] = WORST;
     float thr_f = -INFINITY;                                           // admission threshold (inclusive: a superset is queued)
-    int cnt = 0;                                                       // pending entries of this lane: a STACK (slot = cnt)
+    // pending entries of this lane: a STACK, addressed by ONE running byte offset wofs = cnt * 512 + lane * 8 into the ring
+    // -- a push is two stores at wofs, wofs + 4 (one ds_write2_b32, any two registers) and one add; the count is wofs >> 9
+    // where it is needed
+    char* ringb = reinterpret_cast<char*>(&ring[0][0]);
+    int wofs = lane * 8;
 
     auto merge16 = [&]() {
         // the newest (up to) 16 pending entries: popping from the top needs no wrap-around and no compaction
+        const int cnt = wofs >> 9;
         const int n = min(cnt, 16), base = cnt - n;
         double key[16];
         int2 raw[16];
@@ -592,7 +597,7 @@ __global__ __launch_bounds__(64) void knn_mfma_bq_kernel(const float* __restrict
             const double kr = knn_key(__int_as_float(raw[r].x), raw[r].y & 0xFFFFF);
             key[r] = r < n ? kr : WORST;
         }
-        cnt = base;
+        wofs = base * 512 + lane * 8;
 #pragma unroll
         for (int kb = 2; kb <= 16; kb <<= 1)
 #pragma unroll
@@ -695,19 +700,20 @@ __global__ __launch_bounds__(64) void knn_mfma_bq_kernel(const float* __restrict
                     const int j = c0 + ((r + h) & 3) + 8 * ((r + h) >> 2) + 4 * lk;
                     const float sc = h ? sc2.y : sc2.x;
                     if ((decltype(whole)::value || j < N) && sc >= thr_f) {
-                        ring[cnt][lane] = make_int2(__float_as_int(sc), j);
-                        ++cnt;
+                        *reinterpret_cast<int*>(ringb + wofs) = __float_as_int(sc);
+                        *reinterpret_cast<int*>(ringb + wofs + 4) = j;
+                        wofs += 512;
                     }
                 }
             }
         };
         if (full) scan(std::true_type{});
         else scan(std::false_type{});
-        if (__any(cnt > 16)) merge16();            // afterwards every lane holds <= 16: room for the next tile's 16
+        if (__any(wofs >= 17 * 512)) merge16();    // some lane holds > 16; afterwards every lane holds <= 16: room for 16 more
 #pragma unroll
         for (int r = 0; r < 16; ++r) sqj[r] = sqn[r];
     }
-    while (__any(cnt > 0)) merge16();
+    while (__any(wofs >= 512)) merge16();
     // two sorted lists per query (lanes l, l + 32) -> LDS -> one thread per query merges
     double (*lkey)[2][32] = reinterpret_cast<double (*)[2][32]>(&ring[0][0]);          // (all pending keys are merged)
 #pragma unroll
