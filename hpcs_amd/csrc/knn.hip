@@ -581,22 +581,26 @@ __global__ __launch_bounds__(64) void knn_mfma_bq_kernel(const float* __restrict
     // where it is needed
     char* ringb = reinterpret_cast<char*>(&ring[0][0]);
     int wofs = lane * 8;
+#pragma unroll
+    for (int r = 0; r < BQ_RING; ++r) *reinterpret_cast<int*>(ringb + wofs + r * 512) = (int)0xFF800000u;   // every slot: score -inf
 
     auto merge16 = [&]() {
-        // the newest (up to) 16 pending entries: popping from the top needs no wrap-around and no compaction
+        // the newest (up to) 16 pending entries: popping from the top needs no wrap-around and no compaction.  Slots above a
+        // lane's top always hold a score of -inf (set at start, restored after every pop), so a lane with fewer than 16 pending
+        // entries pads its batch with keys below every real one without any per-key select.
         const int cnt = wofs >> 9;
-        const int n = min(cnt, 16), base = cnt - n;
+        const int base = max(cnt - 16, 0);
         double key[16];
         int2 raw[16];
+        const int rofs = base * 512 + lane * 8;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) raw[r] = ring[base + r][lane];      // 16 reads in flight together (base <= 16)
+        for (int r = 0; r < 16; ++r) raw[r] = *reinterpret_cast<const int2*>(ringb + rofs + r * 512);   // 16 reads in flight
 #pragma unroll
-        for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(raw[r].x), "+v"(raw[r].y));     // (not sunk into the selects)
+        for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(raw[r].x), "+v"(raw[r].y));     // (not sunk below the stores)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const double kr = knn_key(__int_as_float(raw[r].x), raw[r].y & 0xFFFFF);
-            key[r] = r < n ? kr : WORST;
-        }
+        for (int r = 0; r < 16; ++r) *reinterpret_cast<int*>(ringb + rofs + r * 512) = (int)0xFF800000u;  // popped: -inf again
+#pragma unroll
+        for (int r = 0; r < 16; ++r) key[r] = knn_key(__int_as_float(raw[r].x), raw[r].y & 0xFFFFF);
         wofs = base * 512 + lane * 8;
 #pragma unroll
         for (int kb = 2; kb <= 16; kb <<= 1)
