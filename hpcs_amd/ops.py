@@ -65,6 +65,12 @@ def _zeros64(n, device):
 
 
 BN_FOLD = __import__("os").environ.get("HPCS_BN_FOLD", "1") != "0"     # A/B: 0 = statistics and finalisation as two launches
+BN_FOLD_MAX = 1 << 20      # elements per channel up to which the fold is used: every workgroup of a statistics kernel pays a
+#                            ticket (+9 us per kernel at 655 k elements: what the finalise launch cost; +20 us at 1.3 M: more)
+
+
+def _bn_fold(count):
+    return BN_FOLD and count <= BN_FOLD_MAX
 
 
 def _zeros64_ticket(n, device):
@@ -568,7 +574,7 @@ class VNLayerFn(torch.autograd.Function):
         if flags & VN_BN:
             mean = torch.empty(Cout, device=dev)
             rstd = torch.empty(Cout, device=dev)
-            if training and not BN_FOLD:
+            if training and not _bn_fold(B * L):
                 sums = _zeros64(2 * Cout, dev)
                 call("hpcs_vn_norm_stats", PD, B, Cout, Ctot, L, sums, 1)
                 call("hpcs_bn_finalize", sums, Cout, B * L, BN_EPS, BN_MOMENTUM, rmean, rvar, mean, rstd, 1)
@@ -801,7 +807,7 @@ class VNGraphLayerFn(torch.autograd.Function):
             # two input channels (conv1): PD = W E is two fmas per value -- formed inside the point-wise kernels from the
             # 16 MB edge tensor, bit-identical to the GEMM's chain, instead of a 330 MB tensor written once and read 4 times
             PD, ldw = E, WxP.Wp.shape[1]
-            if training and not BN_FOLD:
+            if training and not _bn_fold(B * L):
                 call("hpcs_vn_norm_stats_k2", E, WxP.Wp, ldw, B, Cout, Ctot, L, sums, 1)
                 call("hpcs_bn_finalize", sums, Cout, B * L, BN_EPS, BN_MOMENTUM, rmean, rvar, mean, rstd, 1)
             elif training:
@@ -810,7 +816,7 @@ class VNGraphLayerFn(torch.autograd.Function):
         else:
             PD = gemm_WX(WxP, E, B, 2 * C, 3 * L)
             del E
-            if training and not BN_FOLD:
+            if training and not _bn_fold(B * L):
                 call("hpcs_vn_norm_stats", PD, B, Cout, Ctot, L, sums, 1)
                 call("hpcs_bn_finalize", sums, Cout, B * L, BN_EPS, BN_MOMENTUM, rmean, rvar, mean, rstd, 1)
             elif training:
@@ -940,7 +946,7 @@ class BnActFn(torch.autograd.Function):
         dev = y.device
         mean = torch.empty(C, device=dev)
         rstd = torch.empty(C, device=dev)
-        if training and not BN_FOLD:
+        if training and not _bn_fold(B * L):
             sums = _zeros64(2 * C, dev)
             call("hpcs_bn_stats", y, B, C, L, sums, 1)
             call("hpcs_bn_finalize", sums, C, B * L, BN_EPS, BN_MOMENTUM, rmean, rvar, mean, rstd, 1)
