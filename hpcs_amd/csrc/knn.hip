@@ -550,15 +550,19 @@ __global__ __launch_bounds__(NW * 64) void knn_mfma_queue_kernel(const float* __
 // included.  Thresholds are stale between merges (a superset is queued); the merge itself decides.  Expected per list of 512
 // candidates: ~60-100 appended keys, ~8-12 merges per wave.
 constexpr int BQ_RING = 32;    // pending slots per lane: a tile appends at most 16, a merge leaves at most 16
-template <int KSTEPS, int KK>
-__global__ __launch_bounds__(64) void knn_mfma_bq_kernel(const float* __restrict__ x, const float* __restrict__ sq, int D, int N,
-                                                        int k, int64_t* __restrict__ idx) {
+// NW = 2: two waves share a query tile and take alternate candidate tiles (four lists per query) -- for launches with fewer
+// than two waves per SIMD (B=32, N=1024: a D=63 wave is a chain of 32 x 32 dependent MFMAs per tile) and for k = 33..40 on
+// 32-wide lists, where the final merge flags a tile whenever one list would have had to supply more than its 32 entries
+// (`redo`, repaired by the queued kernel exactly as behind the sorting-network kernel).
+template <int KSTEPS, int KK, int NW>
+__global__ __launch_bounds__(64 * NW) void knn_mfma_bq_kernel(const float* __restrict__ x, const float* __restrict__ sq, int D, int N,
+                                                             int k, int64_t* __restrict__ idx, int* __restrict__ redo) {
     static_assert(KK <= 32, "the merge network is 32 wide");
-    __shared__ int2 ring[BQ_RING][64];                     // (score bits, index); 16 KB, reused for the final two-list merge
+    __shared__ int2 ring[NW][BQ_RING][64];                 // (score bits, index); 16 KB per wave, reused for the final merge
     const int tiles_q = (N + MQ - 1) / MQ;
     const int b = blockIdx.x / tiles_q;
     const int q0 = (blockIdx.x % tiles_q) * MQ;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int lr = lane & 31, lk = lane >> 5;
     const float* xb = x + (int64_t)b * D * N;
     const float* sqb = sq + (int64_t)b * N;
@@ -579,7 +583,7 @@ __global__ __launch_bounds__(64) void knn_mfma_bq_kernel(const float* __restrict
     // pending entries of this lane: a STACK, addressed by ONE running byte offset wofs = cnt * 512 + lane * 8 into the ring
     // -- a push is two stores at wofs, wofs + 4 (one ds_write2_b32, any two registers) and one add; the count is wofs >> 9
     // where it is needed
-    char* ringb = reinterpret_cast<char*>(&ring[0][0]);
+    char* ringb = reinterpret_cast<char*>(&ring[w][0][0]);
     int wofs = lane * 8;
 #pragma unroll
     for (int r = 0; r < BQ_RING; ++r) *reinterpret_cast<int*>(ringb + wofs + r * 512) = (int)0xFF800000u;   // every slot: score -inf
@@ -646,7 +650,7 @@ __global__ __launch_bounds__(64) void knn_mfma_bq_kernel(const float* __restrict
     const bool sq_vec = (N % 4 == 0) && ((((uintptr_t)sq) & 15u) == 0);
     float af[KSTEPS];
     {
-        const int ci = lr;
+        const int ci = w * 32 + lr;
 #pragma unroll
         for (int kk = 0; kk < KSTEPS; ++kk) {
             const int d = 2 * kk + lk;
@@ -671,18 +675,18 @@ __global__ __launch_bounds__(64) void knn_mfma_bq_kernel(const float* __restrict
             }
         }
     };
-    load_sq(0, sqj);
+    load_sq(w * 32, sqj);
 #pragma unroll
     for (int r = 0; r < 16; ++r) sqn[r] = 0.f;
-    for (int t = 0; t < ntile; ++t) {
+    for (int t = w; t < ntile; t += NW) {
         const int c0 = t * 32;
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
         for (int kk = 0; kk < KSTEPS; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk], bq[kk], acc, 0, 0, 0);
-        if (t + 1 < ntile) {                       // next tile's candidate operand is in flight during the selection
-            const int ci = c0 + 32 + lr;
+        if (t + NW < ntile) {                      // next tile's candidate operand is in flight during the selection
+            const int ci = c0 + 32 * NW + lr;
 #pragma unroll
             for (int kk = 0; kk < KSTEPS; ++kk) {
                 const int d = 2 * kk + lk;
@@ -690,7 +694,7 @@ __global__ __launch_bounds__(64) void knn_mfma_bq_kernel(const float* __restrict
             }
         }
         const bool full = c0 + 32 <= N;
-        if (t + 1 < ntile) load_sq(c0 + 32, sqn);  // ... and its |x|^2 (the tile's own arrived during the previous tile)
+        if (t + NW < ntile) load_sq(c0 + 32 * NW, sqn);  // ... and its |x|^2 (the tile's own arrived during the previous tile)
         auto scan = [&](auto whole) {              // whole tile inside the cloud: no per-candidate bound test
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
@@ -718,22 +722,36 @@ __global__ __launch_bounds__(64) void knn_mfma_bq_kernel(const float* __restrict
         for (int r = 0; r < 16; ++r) sqj[r] = sqn[r];
     }
     while (__any(wofs >= 512)) merge16();
-    // two sorted lists per query (lanes l, l + 32) -> LDS -> one thread per query merges
-    double (*lkey)[2][32] = reinterpret_cast<double (*)[2][32]>(&ring[0][0]);          // (all pending keys are merged)
+    // 2 * NW sorted lists per query (lanes l, l + 32 of every wave) -> LDS -> one thread per query merges
+    if (NW > 1) __syncthreads();                                       // every wave is done with its pending stack
+    double (*lkey)[2 * NW][32] = reinterpret_cast<double (*)[2 * NW][32]>(&ring[0][0][0]);
 #pragma unroll
-    for (int m = 0; m < KK; ++m) lkey[lr][lk][m] = lst[m];
+    for (int m = 0; m < KK; ++m) lkey[lr][2 * w + lk][m] = lst[m];
     __syncthreads();
-    if (lane < MQ && q0 + lane < N) {
-        int h0 = 0, h1 = 0;
-        int64_t* o = idx + ((int64_t)b * N + q0 + lane) * k;
+    if (threadIdx.x < MQ && q0 + (int)threadIdx.x < N) {
+        const int q = threadIdx.x;
+        int head[2 * NW];
+#pragma unroll
+        for (int u = 0; u < 2 * NW; ++u) head[u] = 0;
+        int64_t* o = idx + ((int64_t)b * N + q0 + q) * k;
         for (int m = 0; m < k; ++m) {
-            const double a = h0 < KK ? lkey[lane][0][h0] : 0.0;
-            const double c = h1 < KK ? lkey[lane][1][h1] : 0.0;
-            const bool ta = a > c;
-            const double bestk = ta ? a : c;
-            h0 += ta ? 1 : 0;
-            h1 += ta ? 0 : 1;
+            double bestk = 0.0;
+            int bu = 0;
+#pragma unroll
+            for (int u = 0; u < 2 * NW; ++u) {
+                const int h = head[u];
+                const double v = h < KK ? lkey[q][u][h] : 0.0;
+                if (v > bestk) { bestk = v; bu = u; }
+            }
+#pragma unroll
+            for (int u = 0; u < 2 * NW; ++u) head[u] += (u == bu) ? 1 : 0;
             o[m] = (int64_t)knn_key_index(bestk);
+        }
+        if (redo && k > KK) {                                          // a list that ran dry may have owed more than KK entries
+            bool exhausted = false;
+#pragma unroll
+            for (int u = 0; u < 2 * NW; ++u) exhausted = exhausted || head[u] >= KK;
+            if (exhausted) redo[blockIdx.x] = 1;
         }
     }
 }
@@ -750,21 +768,33 @@ int launch_knn_mfma(const float* x, const float* sq, int B, int D, int N, int k,
     // r02: sorting network on 32-wide lists + flagged exact repair (see knn_mfma_sort_kernel): measured below.
     // So: k <= 32 -> sorting network; 32 < k <= 40 -> sorting network with 32-wide lists + repair pass of the queued kernel.
     const char* e = getenv("HPCS_KNN_KERNEL");     // tiled|insert|queue|bq overrides the choice (A/B tests; read on every call)
-    const int force = !e ? 0 : (e[0] == 't' ? 1 : (e[0] == 'i' ? 3 : (e[0] == 'b' ? 4 : 2)));  // tiled (sorting network) | insert | bq | queue
+    const int force = !e ? 0 : (e[0] == 't' ? 1 : (e[0] == 'i' ? 3 : (e[0] == 'b' ? (e[1] == 'q' && e[2] == '2' ? 5 : 4) : 2)));
+    // tiled (sorting network) | insert | bq | bq2 | queue
     const bool tiled = force == 1 || force == 3 || (force == 0 && k <= 32);
     // k <= 32: the batch-queue kernel (one wave per 32 queries) once there is a wave per SIMD, the 4-wave sorting-network
-    // kernel for small batches (B=8, N=500: 32 vs 58 us; B=32, N=1024: 60 vs 60 (D=3), 132 vs 118 (D=63); B=4096: 5215 vs 3316)
-    const bool bq = force == 4 || (force == 0 && k <= 32 && (long)grid.x >= 1024);
-    if (k > 32 && redo && (force == 0 || force == 1)) {
+    // kernel for small batches (B=8, N=500 D=63: 31 vs 50 us; B=32, N=1024: 57 vs 40 (D=3), 129 vs 95 (D=63) with two waves per
+    // query tile; B=4096: 4935 vs 2585 with one)
+    const bool bq = force == 4 || force == 5 || (force == 0 && k <= 32 && (long)grid.x >= 1024);
+    // two waves per query tile while the launch has fewer than two one-wave workgroups per SIMD (HPCS_KNN_KERNEL=bq2 forces it)
+    const bool bq2 = force == 5 || (force == 0 && (long)grid.x < 2048);
+    if (k > 32 && redo && (force == 0 || force == 1 || force == 5)) {
         if (hipMemsetAsync(redo, 0, sizeof(int) * grid.x, st) != hipSuccess) return HPCS_ERR_HIP;
-        hipLaunchKernelGGL((knn_mfma_sort_kernel<KSTEPS, 32>), grid, dim3(MW * 64), 0, st, x, sq, D, N, k, idx, redo);
+        // B=16, N=2048, k=40: two-wave batch-queue 78 us vs sorting network 154 us at D=3; 229 vs 233 us at D=63 (kept on the network)
+        if (force == 5 || (force == 0 && KSTEPS == 2))
+            hipLaunchKernelGGL((knn_mfma_bq_kernel<KSTEPS, 32, 2>), grid, dim3(128), 0, st, x, sq, D, N, k, idx, redo);
+        else
+            hipLaunchKernelGGL((knn_mfma_sort_kernel<KSTEPS, 32>), grid, dim3(MW * 64), 0, st, x, sq, D, N, k, idx, redo);
         hipLaunchKernelGGL((knn_mfma_queue_kernel<KSTEPS, 40, 1>), grid, dim3(64), 0, st, x, sq, D, N, k, idx, (const int*)redo);
         return HPCS_OK;
     }
 #define HPCS_KNNM_CASE(KK)                                                                                   \
     if (k <= KK) {                                                                                            \
-        if (bq && KK <= 32)                                                                                   \
-            hipLaunchKernelGGL((knn_mfma_bq_kernel<KSTEPS, (KK <= 32 ? KK : 32)>), grid, dim3(64), 0, st, x, sq, D, N, k, idx); \
+        if (bq && KK <= 32 && bq2)                                                                            \
+            hipLaunchKernelGGL((knn_mfma_bq_kernel<KSTEPS, (KK <= 32 ? KK : 32), 2>), grid, dim3(128), 0, st, x, sq, D, N, k, idx, \
+                               (int*)nullptr);                                                                \
+        else if (bq && KK <= 32)                                                                              \
+            hipLaunchKernelGGL((knn_mfma_bq_kernel<KSTEPS, (KK <= 32 ? KK : 32), 1>), grid, dim3(64), 0, st, x, sq, D, N, k, idx, \
+                               (int*)nullptr);                                                                \
         else if (tiled && KK <= 32 && force != 3)                                                                  \
             hipLaunchKernelGGL((knn_mfma_sort_kernel<KSTEPS, (KK <= 32 ? KK : 32)>), grid, dim3(MW * 64), 0, st, x, sq, D, N, k, \
                                idx, (int*)nullptr);                                                           \
