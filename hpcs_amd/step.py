@@ -93,7 +93,6 @@ class HypHCStep(torch.nn.Module):
         self.graph_auto = mode == "auto"
         self.graph_warmup = 3               # eager steps before the capture (allocator pools, lazily built tables)
         self._graph = None
-        self._graph_serial = False             # captured without the weight-gradient side stream (auto mode's third candidate)
         self._prep_cache = PrepCache()                 # rebuilt in configure() once the parameters are on the device
         self._eager_steps = 0
         self._tune = None                   # auto mode: {"phase", "t": {"eager": [...], "graph": [...]}, "ev"}
@@ -265,7 +264,9 @@ class HypHCStep(torch.nn.Module):
             import torch.distributed as dist
             if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
                 self.use_graph = False
-        return (self.use_graph and targets_host is not None and rot is None and drop_masks is None and loss.miner
+        # (only the form with the weight-gradient side stream is replayed: the single-stream capture corrupts the returned
+        # metric outputs after convergence, DESIGN.md "Round 2: ... weighed and not built")
+        return (self.use_graph and self.side_stream_wgrad and targets_host is not None and rot is None and drop_masks is None and loss.miner
                 and loss.fused_filter and loss.hyp_miner.rng == "device" and loss.debug_triplets is None
                 and self.train_rotation in ("so3", None) and self.training)
 
@@ -290,14 +291,13 @@ class HypHCStep(torch.nn.Module):
         return self._eager_step(points, label, targets, targets_host, rot, drop_masks)
 
     def _auto_mode(self):
-        """auto mode schedule after the warm-up: capture + first replay (untimed) and 2 timed replays of the step with its
-        side stream; that capture is FREED, the step is captured again without the side stream (small clouds: the fork /
-        join nodes cost more than overlapping micro-second GEMMs gives) and replayed 1 + 2 times; 2 timed eager steps; then
-        the fastest of the three for good (a winning first form is captured once more).  Never two captures alive: holding
-        both and freeing the loser made long runs unstable.  Times are event spans of whole steps enqueued back to back."""
+        """auto mode schedule after the warm-up: capture + first replay (untimed), 2 timed replays, 2 timed eager steps,
+        then the faster mode for good.  Times are event spans of whole steps enqueued back to back.  (A third candidate, the
+        step captured WITHOUT its side stream, is 3 % faster on small clouds but corrupts the in-step metric outputs once
+        training has converged -- see DESIGN.md; it is not offered.)"""
         t = self._tune
         if t is None:
-            t = self._tune = {"n": 0, "graph": [], "graph_serial": [], "eager": [], "pending": None, "choice": None}
+            t = self._tune = {"n": 0, "graph": [], "eager": [], "pending": None, "choice": None}
         if t["choice"] is not None:
             return t["choice"]
         self._collect_timing()
@@ -305,31 +305,16 @@ class HypHCStep(torch.nn.Module):
         if t["n"] <= 3:
             t["kind"] = "graph" if t["n"] > 1 else None            # replay 1 also pays the capture: not timed
             return "graph"
-        if t["n"] <= 6:
-            if t["n"] == 4:
-                torch.cuda.synchronize()
-                self._graph = None                                 # free the first capture before the second is made
-                self._graph_serial = True
-            t["kind"] = "graph_serial" if t["n"] > 4 else None
-            return "graph"
-        if t["n"] <= 8:
+        if t["n"] <= 5:
             t["kind"] = "eager"
             return "eager_timed"
-        g, gs, e = min(t["graph"]), min(t["graph_serial"]), min(t["eager"])
-        t["measured_ms"] = {"graph": g, "graph_serial": gs, "eager": e}
-        if e < g and e < gs:
-            t["choice"] = "eager"
+        g, e = min(t["graph"]), min(t["eager"])
+        t["choice"] = "graph" if g <= e else "eager"
+        t["measured_ms"] = {"graph": g, "eager": e}
+        if t["choice"] == "eager":
             self.use_graph = False
-            torch.cuda.synchronize()
-            self._graph = None
-            self._graph_serial = False
         else:
-            t["choice"] = "graph"
             self.graph_auto = False
-            if g <= gs:                                            # back to the side-stream form: captured anew on this step
-                torch.cuda.synchronize()
-                self._graph = None
-                self._graph_serial = False
         return t["choice"]
 
     def graph_mode(self):
@@ -339,10 +324,6 @@ class HypHCStep(torch.nn.Module):
         if not self.graph_auto:
             return "graph"
         return None if self._tune is None or self._tune["choice"] is None else self._tune["choice"]
-
-    def graph_variant(self):
-        """'side-stream' | 'serial': how the replayed step was captured."""
-        return "serial" if self._graph_serial else "side-stream"
 
     def _collect_timing(self):
         t = self._tune
@@ -385,16 +366,10 @@ class HypHCStep(torch.nn.Module):
             ctx.T_grid = g["T_cap"]
             torch.cuda.synchronize()
             g["fwd_bwd"] = torch.cuda.CUDAGraph()
-            side = self.side_stream_wgrad
-            if self._graph_serial:
-                self.side_stream_wgrad = False
-            try:
-                with torch.cuda.graph(g["fwd_bwd"], capture_error_mode="thread_local"):
-                    g["out"] = self._backward_part(*g["in"], ctx, None, None)
-                    if world == 1:
-                        self.optimizer.step(tables=ctx.radam_tables, tables_dev=ctx.radam_dev)
-            finally:
-                self.side_stream_wgrad = side
+            with torch.cuda.graph(g["fwd_bwd"], capture_error_mode="thread_local"):
+                g["out"] = self._backward_part(*g["in"], ctx, None, None)
+                if world == 1:
+                    self.optimizer.step(tables=ctx.radam_tables, tables_dev=ctx.radam_dev)
             if world > 1:
                 g["pool"] = g["fwd_bwd"].pool()
                 g["opt"] = torch.cuda.CUDAGraph()
