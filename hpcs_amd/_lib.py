@@ -107,8 +107,62 @@ PROFILE = None
 PROFILE_FILTER = None      # optional callable(name, shape_tag) -> bool: time only the launches it accepts
 
 
+class Watch:
+    """Diagnostics: a stream-ordered watchpoint (csrc/debug.hip).  Once armed on a device region, one compare kernel is
+    enqueued after EVERY later entry-point call (also inside a hipGraph capture, also from autograd's backward thread);
+    status[0] then names the first call after which the region no longer matched its snapshot: `names[status[0] - 1]`.
+    Nothing is allocated after construction, so the memory layout of the run under test does not change."""
+
+    def __init__(self, device, nbytes=512):
+        self.nbytes = int(nbytes)
+        self.shadow = torch.zeros(self.nbytes // 4, dtype=torch.int32, device=device)
+        self.status = torch.zeros(8, dtype=torch.int32, device=device)
+        self.names = []
+        self.ptr = None
+        self.armed = False
+        self.frozen = False        # True: keep the names of the first armed pass (a capture) and stop recording
+
+    def arm(self, ptr):
+        """Snapshot the region at `ptr` (device address) and start watching it."""
+        self.ptr = int(ptr)
+        _call("hpcs_debug_snapshot", self.ptr, self.shadow, self.nbytes)
+        if not self.frozen:
+            self.names = []
+        self._seq = 0
+        self.armed = True
+
+    def disarm(self):
+        self.armed = False
+
+    def check(self, label):
+        """One compare kernel now (torch-op boundaries that no entry point brackets)."""
+        if not self.armed:
+            return
+        self._seq += 1
+        if not self.frozen:
+            self.names.append(label)
+        _call("hpcs_debug_watch", self.ptr, self.shadow, self.nbytes, self._seq, self.status)
+
+    def report(self):
+        st = [int(v) for v in self.status.cpu()]
+        if st[0] == 0:
+            return None
+        seq = st[0]
+        return {"seq": seq, "after": self.names[seq - 1] if 0 < seq <= len(self.names) else None,
+                "previous": self.names[seq - 2] if 1 < seq <= len(self.names) + 1 else None,
+                "word": st[1], "found": st[2] & 0xffffffff, "expected": st[3] & 0xffffffff, "differing_words": st[4],
+                "next_word": st[5] & 0xffffffff, "checks": st[6], "check_at_hit": st[7], "calls_per_pass": len(self.names)}
+
+
+WATCH = None               # a Watch instance while a hunt is on (scripts/fault_hunt.py); None in every normal run
+
+
 def call(name, *args, tag=None):
     """Calls an entry point; tensors become device pointers, the stream argument is appended."""
+    if WATCH is not None and WATCH.armed and not name.endswith("_workspace"):
+        rc = _call(name, *args)
+        WATCH.check((name, tag if tag is not None else _shape_tag(name, args)))
+        return rc
     if PROFILE is not None and name in PROFILE:
         tg = tag if tag is not None else _shape_tag(name, args)
         if PROFILE_FILTER is None or PROFILE_FILTER(name, tg):

@@ -15,6 +15,49 @@
 
 static inline int hpcs_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Zero-fill of up to four buffers as ONE ordinary kernel launch.  This library never calls hipMemsetAsync: on this runtime
+// (ROCm 7.0 / 7.2, graph packet capture on) the memset NODES of a replayed hipGraph lose their arguments once a second
+// graph has been instantiated -- after a device-wide synchronize, or after a few thousand node launches, the fill writes
+// a stale 64-bit pattern (and, for other nodes, to a stale address: a GPU memory-access fault).  That was round 2's
+// "stray store" (DESIGN.md); scripts/graph_lifetime_repro2.py reproduces it with hipMemsetAsync + two kernels.  Kernel
+// nodes replay correctly, and one launch instead of three memset nodes is cheaper as well.
+struct HpcsZeroJob {
+    void* p[4];
+    unsigned long long n[4];      // bytes, multiples of 4
+};
+static __global__ void hpcs_zero_kernel(HpcsZeroJob job) {
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        char* p = (char*)job.p[j];
+        const size_t n = job.n[j];
+        if (p == nullptr || n == 0) continue;
+        if ((((size_t)p | n) & 15) == 0) {
+            uint4* q = (uint4*)p;
+            for (size_t i = tid; i < (n >> 4); i += nth) q[i] = make_uint4(0u, 0u, 0u, 0u);
+        } else {
+            unsigned* q = (unsigned*)p;
+            for (size_t i = tid; i < (n >> 2); i += nth) q[i] = 0u;
+        }
+    }
+}
+static inline int hpcs_zero_async(hipStream_t st, void* p0, size_t n0, void* p1 = nullptr, size_t n1 = 0, void* p2 = nullptr,
+                                  size_t n2 = 0, void* p3 = nullptr, size_t n3 = 0) {
+    HpcsZeroJob job{{p0, p1, p2, p3}, {n0, n1, n2, n3}};
+    size_t mx = 0;
+    for (int j = 0; j < 4; ++j) {
+        if (job.p[j] == nullptr) job.n[j] = 0;
+        if (job.n[j] & 3) return HPCS_ERR_SHAPE;
+        if (job.n[j] > mx) mx = job.n[j];
+    }
+    if (mx == 0) return HPCS_OK;
+    long blocks = (long)((mx + 256 * 64 - 1) / (256 * 64));       // 64 bytes per thread per pass
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(hpcs_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, st, job);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? HPCS_OK : HPCS_ERR_HIP - (int)e;
+}
+
 // Bijective XCD-aware block remap (cdna_hip_programming.md T1): hardware deals consecutive
 // block ids round-robin over the 8 XCDs; give each XCD a contiguous run of logical ids so that
 // neighbouring tiles (which share operand panels) hit the same L2.

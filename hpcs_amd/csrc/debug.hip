@@ -1,0 +1,61 @@
+// Diagnostics only (no reference counterpart): a stream-ordered WATCHPOINT on a small device region.
+//
+// hpcs_debug_snapshot copies the watched bytes into a shadow buffer; hpcs_debug_watch, enqueued after every later
+// launch (hpcs_amd/_lib.py, HPCS_WATCH), compares the region with its shadow and records the sequence number of the FIRST
+// launch after which they differ.  Both are ordinary kernels, so they are captured into a hipGraph with the step and
+// bracket every captured node; neither allocates, so the memory layout of the run under test is unchanged.  This is how
+// the stray store of round 2 (DESIGN.md "The stray store") was attributed to its kernel.
+#include "common.h"
+
+namespace {
+
+__global__ void debug_snapshot_kernel(const unsigned* __restrict__ src, unsigned* __restrict__ dst, int nwords) {
+    for (int i = threadIdx.x; i < nwords; i += blockDim.x) dst[i] = src[i];
+}
+
+// status[0] first sequence number with a mismatch (0: none yet), [1] word offset of the first differing word,
+// [2] value found, [3] value expected, [4] number of differing words at that moment, [5] the word after it (an 8-byte
+// store shows as two), [6] launches checked so far (all replays), [7] value of [6] when the mismatch was first seen
+__global__ void debug_watch_kernel(const unsigned* __restrict__ watched, const unsigned* __restrict__ shadow, int nwords, int seq,
+                                   int* __restrict__ status) {
+    __shared__ int first, count;
+    if (threadIdx.x == 0) { first = 0x7fffffff; count = 0; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nwords; i += blockDim.x)
+        if (watched[i] != shadow[i]) { atomicMin(&first, i); atomicAdd(&count, 1); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int n = ++status[6];
+        if (count > 0 && status[0] == 0) {
+            status[0] = seq;
+            status[1] = first;
+            status[2] = (int)watched[first];
+            status[3] = (int)shadow[first];
+            status[4] = count;
+            status[5] = first + 1 < nwords ? (int)watched[first + 1] : 0;
+            status[7] = n;
+        }
+    }
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int hpcs_debug_snapshot(const void* src, void* dst, int nbytes, hpcs_stream_t stream) {
+    if (!src || !dst) return HPCS_ERR_NULL;
+    if (nbytes <= 0 || nbytes % 4) return HPCS_ERR_SHAPE;
+    hipLaunchKernelGGL(debug_snapshot_kernel, dim3(1), dim3(256), 0, ST, (const unsigned*)src, (unsigned*)dst, nbytes / 4);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
+extern "C" int hpcs_debug_watch(const void* watched, const void* shadow, int nbytes, int seq, int32_t* status,
+                                hpcs_stream_t stream) {
+    if (!watched || !shadow || !status) return HPCS_ERR_NULL;
+    if (nbytes <= 0 || nbytes % 4) return HPCS_ERR_SHAPE;
+    hipLaunchKernelGGL(debug_watch_kernel, dim3(1), dim3(256), 0, ST, (const unsigned*)watched, (const unsigned*)shadow,
+                       nbytes / 4, seq, (int*)status);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}

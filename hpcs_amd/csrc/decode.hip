@@ -533,8 +533,7 @@ extern "C" int hpcs_complete_linkage(const float* leaves, int B, int N, int E, d
     char* base = (char*)ws;
     double* D = (double*)(base + w.d);
     double* nrm = (double*)(base + w.nrm);
-    hipError_t e = hipMemsetAsync(status, 0, sizeof(int32_t) * B, s);
-    if (e != hipSuccess) return HPCS_ERR_HIP - (int)e;
+    if (const int zr = hpcs_zero_async(s, status, sizeof(int32_t) * B)) return zr;
     const long rows = (long)B * N;
     leaf_norms_kernel<<<hpcs_cdiv(rows, 256), 256, 0, s>>>(leaves, E, rows, nrm);
     HPCS_CHECK_LAUNCH();

@@ -521,7 +521,7 @@ extern "C" int hpcs_l2_rows_bwd(const float* xn, const float* inv_norm, const fl
 extern "C" int hpcs_colsum(const float* xn, int64_t rows, int E, double* colsum, hpcs_stream_t stream) {
     if (!xn || !colsum) return HPCS_ERR_NULL;
     if (!ROW_ARGS_OK(rows, E)) return HPCS_ERR_SHAPE;
-    if (hipMemsetAsync(colsum, 0, sizeof(double) * E, ST) != hipSuccess) return HPCS_ERR_HIP;
+    if (const int zr = hpcs_zero_async(ST, colsum, sizeof(double) * E)) return zr;
     if (rows == 0) return HPCS_OK;
     if (E <= 256 && (E & (E - 1)) == 0)
         hipLaunchKernelGGL(colsum_pow2_kernel, dim3(hpcs_cdiv(rows, 256)), dim3(256), 0, ST, xn, rows, E, colsum);

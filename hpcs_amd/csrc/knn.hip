@@ -778,7 +778,7 @@ int launch_knn_mfma(const float* x, const float* sq, int B, int D, int N, int k,
     // two waves per query tile while the launch has fewer than two one-wave workgroups per SIMD (HPCS_KNN_KERNEL=bq2 forces it)
     const bool bq2 = force == 5 || (force == 0 && (long)grid.x < 2048);
     if (k > 32 && redo && (force == 0 || force == 1 || force == 5)) {
-        if (hipMemsetAsync(redo, 0, sizeof(int) * grid.x, st) != hipSuccess) return HPCS_ERR_HIP;
+        if (const int zr = hpcs_zero_async(st, redo, sizeof(int) * grid.x)) return zr;
         // B=16, N=2048, k=40: two-wave batch-queue 78 us vs sorting network 154 us at D=3; 229 vs 233 us at D=63 (kept on the network)
         if (force == 5 || (force == 0 && KSTEPS == 2))
             hipLaunchKernelGGL((knn_mfma_bq_kernel<KSTEPS, 32, 2>), grid, dim3(128), 0, st, x, sq, D, N, k, idx, redo);

@@ -1365,7 +1365,7 @@ extern "C" int hpcs_class_index(const int64_t* labels, int M, int C, int32_t* or
         HPCS_CHECK_LAUNCH();
         return HPCS_OK;
     }
-    if (hipMemsetAsync(counts_ws, 0, sizeof(int32_t) * C, ST) != hipSuccess) return HPCS_ERR_HIP;
+    if (const int zr = hpcs_zero_async(ST, counts_ws, sizeof(int32_t) * C)) return zr;
     if (M > 0) {
         hipLaunchKernelGGL(hist_kernel, dim3(hpcs_cdiv(M, TPB)), dim3(TPB), 0, ST, labels, M, C, counts_ws);
         HPCS_CHECK_LAUNCH();
@@ -1406,8 +1406,7 @@ extern "C" int hpcs_triplet_filter(const float* xn, int E, const int64_t* a, con
     if (E <= 0 || T < 0 || kind < 0 || kind > 3) return HPCS_ERR_SHAPE;
     if (ws_bytes < hpcs_triplet_filter_workspace(T)) return HPCS_ERR_WORKSPACE;
     if (T == 0) {
-        if (hipMemsetAsync(count, 0, sizeof(int64_t), ST) != hipSuccess) return HPCS_ERR_HIP;
-        return HPCS_OK;
+        return hpcs_zero_async(ST, count, sizeof(int64_t));
     }
     const int64_t nb = (T + CHUNK - 1) / CHUNK;
     uint8_t* flags = (uint8_t*)ws;
@@ -1431,8 +1430,7 @@ extern "C" int hpcs_hyphc_fwd(const float* xn, int E, const int64_t* a, const in
                               int kind, double* loss_sum, int64_t* kept, hpcs_stream_t stream) {
     if (!xn || !a || !p || !n || !count || !scale || !loss_sum) return HPCS_ERR_NULL;
     if (E <= 0 || T_cap < 0 || !(temperature > 0.f) || kind > 3 || (kind >= 0 && !kept)) return HPCS_ERR_SHAPE;
-    if (hipMemsetAsync(loss_sum, 0, sizeof(double), ST) != hipSuccess) return HPCS_ERR_HIP;
-    if (kept && hipMemsetAsync(kept, 0, sizeof(int64_t), ST) != hipSuccess) return HPCS_ERR_HIP;
+    if (const int zr = hpcs_zero_async(ST, loss_sum, sizeof(double), kept, sizeof(int64_t))) return zr;
     if (T_cap == 0) return HPCS_OK;
     const int rc = launch_hyphc<false>(xn, E, a, p, n, count, T_cap, scale, temperature, margin, kind, nullptr,
                                        (unsigned long long*)kept, nullptr, loss_sum, nullptr, nullptr, ST);
@@ -1447,9 +1445,7 @@ extern "C" int hpcs_hyphc_bwd(const float* xn, int E, const int64_t* a, const in
                               double* loss_sum, int64_t* kept, hpcs_stream_t stream) {
     if (!xn || !a || !p || !n || !count || !scale || !gloss || !gxn || !gscale) return HPCS_ERR_NULL;
     if (E <= 0 || T_cap < 0 || !(temperature > 0.f) || kind > 3 || (kind >= 0 && !norm_count)) return HPCS_ERR_SHAPE;
-    if (hipMemsetAsync(gscale, 0, sizeof(double), ST) != hipSuccess) return HPCS_ERR_HIP;
-    if (loss_sum && hipMemsetAsync(loss_sum, 0, sizeof(double), ST) != hipSuccess) return HPCS_ERR_HIP;
-    if (kept && hipMemsetAsync(kept, 0, sizeof(int64_t), ST) != hipSuccess) return HPCS_ERR_HIP;
+    if (const int zr = hpcs_zero_async(ST, gscale, sizeof(double), loss_sum, sizeof(double), kept, sizeof(int64_t))) return zr;
     if (T_cap == 0) return HPCS_OK;
     const int rc = launch_hyphc<true>(xn, E, a, p, n, count, T_cap, scale, temperature, margin, kind, norm_count,
                                       (unsigned long long*)kept, gloss, loss_sum, gxn, gscale, ST);
@@ -1482,7 +1478,7 @@ extern "C" int hpcs_cosface_bwd(const float* xn, const float* wn, const int64_t*
     if (!xn || !wn || !labels || !logits || !lse_rows || !gloss || !gxn || !gwn) return HPCS_ERR_NULL;
     if (M < 0 || E <= 0 || C <= 0 || (size_t)C * E * 4 > 64 * 1024) return HPCS_ERR_SHAPE;
     if (n_levels < 1 || n_levels > MAX_LEVELS || (n_levels > 1 && !branch_id)) return HPCS_ERR_SHAPE;
-    if (hipMemsetAsync(gwn, 0, sizeof(float) * C * E, ST) != hipSuccess) return HPCS_ERR_HIP;
+    if (const int zr = hpcs_zero_async(ST, gwn, sizeof(float) * C * E)) return zr;
     if (M == 0) return HPCS_OK;
     const size_t tile_lds = ((size_t)C * E + CF_ROWS * (E + 1) + CF_ROWS * (C + 1)) * 4;
     if (tile_lds <= 64 * 1024 && C * E <= 256 * CF_MAXOUT) {
@@ -1573,7 +1569,7 @@ extern "C" int hpcs_class_metrics(const float* logits, const int64_t* labels, in
                                   hpcs_stream_t stream) {
     if (!logits || !labels || !counts || !acc_iou) return HPCS_ERR_NULL;
     if (M < 0 || C <= 0 || C > 4096) return HPCS_ERR_SHAPE;
-    if (hipMemsetAsync(counts, 0, sizeof(int64_t) * 3 * C, ST) != hipSuccess) return HPCS_ERR_HIP;
+    if (const int zr = hpcs_zero_async(ST, counts, sizeof(int64_t) * 3 * C)) return zr;
     if (M > 0) {
         hipLaunchKernelGGL(class_metrics_kernel, dim3(hpcs_cdiv(M, 256)), dim3(256), sizeof(unsigned) * 3 * C, ST, logits, labels,
                            M, C, (unsigned long long*)counts);
@@ -1590,7 +1586,7 @@ extern "C" int hpcs_triplet_margin_fwd(const float* xn, int E, const int64_t* a,
                                        hpcs_stream_t stream) {
     if (!xn || !a || !p || !n || !count || !sum_and_nnz) return HPCS_ERR_NULL;
     if (E <= 0 || T_cap < 0) return HPCS_ERR_SHAPE;
-    if (hipMemsetAsync(sum_and_nnz, 0, 2 * sizeof(double), ST) != hipSuccess) return HPCS_ERR_HIP;
+    if (const int zr = hpcs_zero_async(ST, sum_and_nnz, 2 * sizeof(double))) return zr;
     if (T_cap == 0) return HPCS_OK;
     hipLaunchKernelGGL(triplet_margin_fwd_kernel, dim3(trip_grid(T_cap)), dim3(TPB), 0, ST, xn, E, a, p, n, count, T_cap,
                        margin, sum_and_nnz);
@@ -1621,9 +1617,7 @@ extern "C" int hpcs_hyphc_sampled(const float* xn, const int64_t* labels, const 
     if ((a_dbg || p_dbg || n_dbg) && !(a_dbg && p_dbg && n_dbg)) return HPCS_ERR_NULL;
     if (C <= 0 || M <= 0 || T < 0 || !(temperature > 0.f) || kind > 3) return HPCS_ERR_SHAPE;
     if (E != 16 && E != 32 && E != 64) return HPCS_ERR_UNSUPPORTED;
-    if (hipMemsetAsync(loss_sum, 0, sizeof(double), ST) != hipSuccess) return HPCS_ERR_HIP;
-    if (hipMemsetAsync(kept, 0, sizeof(int64_t), ST) != hipSuccess) return HPCS_ERR_HIP;
-    if (gscale && hipMemsetAsync(gscale, 0, sizeof(double), ST) != hipSuccess) return HPCS_ERR_HIP;
+    if (const int zr = hpcs_zero_async(ST, loss_sum, sizeof(double), kept, sizeof(int64_t), gscale, sizeof(double))) return zr;
     if (T == 0) return HPCS_OK;
     // Workgroups are resident one per CU (128 KB of LDS), so the grid runs in rounds of n_cu workgroups: pick the
     // segment length (multiple of 8) that wastes the least of the last round; ties go to the longer segment, which

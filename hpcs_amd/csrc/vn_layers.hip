@@ -2172,7 +2172,7 @@ extern "C" int hpcs_edge_gather_bwd(const float* gout, const int64_t* idx, int B
     else
         hipLaunchKernelGGL((edge_gather_bwd_center_kernel<false>), dim3(hpcs_cdiv(N, 64), C, B), dim3(64), 0, ST, gout, C, N, k, gx);
     HPCS_CHECK_LAUNCH();
-    if (hipMemsetAsync(ws, 0, (size_t)B * N * CP * sizeof(float), ST) != hipSuccess) return HPCS_ERR_HIP;
+    if (const int zr = hpcs_zero_async(ST, ws, (size_t)B * N * CP * sizeof(float))) return zr;
     const size_t lds = (size_t)ET * (C * 3 + 1) * sizeof(float);
     if (lds > 64 * 1024) return HPCS_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(edge_scatter_tile_kernel, dim3(hpcs_cdiv(L, ET), B), dim3(256), lds, ST, gout, idx, C, 2 * C, N, k, CP, (float*)ws);
@@ -2197,7 +2197,8 @@ static BnFin bn_fin(unsigned* counter, int64_t count, float eps, float momentum,
 static const BnFin NO_FIN = bn_fin(nullptr, 1, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr);
 
 static int vn_norm_stats_impl(PdRef pd, int B, int Cout, double* sums, int zeroed, hipStream_t st, BnFin fin = NO_FIN) {
-    if (!zeroed && hipMemsetAsync(sums, 0, sizeof(double) * 2 * Cout, st) != hipSuccess) return HPCS_ERR_HIP;
+    if (!zeroed)
+        if (const int zr = hpcs_zero_async(st, sums, sizeof(double) * 2 * Cout)) return zr;
     if (B == 0) return HPCS_OK;
     const bool vec_ok = pd.idx == nullptr && pd.L % 4 == 0 && (((uintptr_t)pd.base & 15u) == 0) && B <= 65535 && Cout <= 65535;
     if (vec_ok && pd.w2 == nullptr)
@@ -2276,7 +2277,8 @@ static int vn_bwd_reduce_impl(PdRef pd, const float* gout, const float* mean, co
                               const float* beta, int B, int Cout, int Cd, int pool_k, float slope, int flags, double* red,
                               int zeroed, hipStream_t st) {
     if (!(flags & HPCS_VN_BN)) return HPCS_ERR_UNSUPPORTED;
-    if (!zeroed && hipMemsetAsync(red, 0, sizeof(double) * 2 * Cout, st) != hipSuccess) return HPCS_ERR_HIP;
+    if (!zeroed)
+        if (const int zr = hpcs_zero_async(st, red, sizeof(double) * 2 * Cout)) return zr;
     if (B == 0) return HPCS_OK;
     const bool vec = pd.idx == nullptr && pd.L % 4 == 0 && (((uintptr_t)pd.base & 15u) == 0) && B <= 65535 && Cout <= 65535 &&
                      (pool_k > 0 ? pool_k % 4 == 0 : (((uintptr_t)gout & 15u) == 0));
@@ -2575,7 +2577,7 @@ static int edge_grad_reduce_impl(const float* GPD, const int64_t* idx, int B, in
     else
         hipLaunchKernelGGL((edge_segsum_kernel<false>), dim3(hpcs_cdiv(N, 64), Ctot, B), dim3(64), 0, ST, GPD, Ctot, N, k, gUV);
     HPCS_CHECK_LAUNCH();
-    if (hipMemsetAsync(ws, 0, (size_t)B * N * CP * sizeof(float), ST) != hipSuccess) return HPCS_ERR_HIP;
+    if (const int zr = hpcs_zero_async(ST, ws, (size_t)B * N * CP * sizeof(float))) return zr;
     const size_t lds = (size_t)ET * (Ctot * 3 + 1) * sizeof(float);
     if (lds > 64 * 1024) return HPCS_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(edge_scatter_tile_kernel, dim3(hpcs_cdiv(L, ET), B), dim3(256), lds, ST, GPD, idx, Ctot, Ctot, N, k, CP,
@@ -2615,7 +2617,8 @@ extern "C" int hpcs_edge_grad_reduce_prebuilt(const float* GPD, int B, int Ctot,
 extern "C" int hpcs_bn_stats(const float* Y, int B, int C, int64_t L, double* sums, int sums_zeroed, hpcs_stream_t stream) {
     if (!Y || !sums) return HPCS_ERR_NULL;
     if (bad_dims(B, C, L) || C > 65535) return HPCS_ERR_SHAPE;
-    if (!sums_zeroed && hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, ST) != hipSuccess) return HPCS_ERR_HIP;
+    if (!sums_zeroed)
+        if (const int zr = hpcs_zero_async(ST, sums, sizeof(double) * 2 * C)) return zr;
     if (B == 0) return HPCS_OK;
     hipLaunchKernelGGL(bn_stats_kernel, dim3(hpcs_cdiv((int64_t)B * L, TPB * ITEMS), C), dim3(TPB), 0, ST, Y, B, C, L, sums, NO_FIN);
     HPCS_CHECK_LAUNCH();
@@ -2646,7 +2649,8 @@ extern "C" int hpcs_bn_act_bwd_reduce(const float* Y, const float* gout, const f
                                       hpcs_stream_t stream) {
     if (!Y || !gout || !mean || !rstd || !gamma || !beta || !red) return HPCS_ERR_NULL;
     if (bad_dims(B, C, L) || C > 65535) return HPCS_ERR_SHAPE;
-    if (!red_zeroed && hipMemsetAsync(red, 0, sizeof(double) * 2 * C, ST) != hipSuccess) return HPCS_ERR_HIP;
+    if (!red_zeroed)
+        if (const int zr = hpcs_zero_async(ST, red, sizeof(double) * 2 * C)) return zr;
     if (B == 0) return HPCS_OK;
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(hpcs_cdiv((int64_t)B * L, TPB * ITEMS), C), dim3(TPB), 0, ST, Y, gout,
                        mean, rstd, gamma, beta, mask, B, C, L, slope, red, (unsigned long long)drop_seed,
@@ -2735,9 +2739,9 @@ extern "C" int hpcs_project_max_bwd(const float* x, const float* xconst, const f
     if (!x || !z || !arg || !gout || (!gx && !gz) || (Cc > 0 && (!xconst || (gz && !gxconst)))) return HPCS_ERR_NULL;
     if (B < 0 || C <= 0 || Cc < 0 || N <= 0) return HPCS_ERR_SHAPE;
     if (B == 0) return HPCS_OK;
-    if (gx && !gx_accumulate && hipMemsetAsync(gx, 0, sizeof(float) * (size_t)B * C * 3 * N, ST) != hipSuccess)
-        return HPCS_ERR_HIP;
-    if (gz && hipMemsetAsync(gz, 0, sizeof(float) * (size_t)B * 9 * N, ST) != hipSuccess) return HPCS_ERR_HIP;
+    if (const int zr = hpcs_zero_async(ST, (gx && !gx_accumulate) ? gx : nullptr, sizeof(float) * (size_t)B * C * 3 * N, gz,
+                                       sizeof(float) * (size_t)B * 9 * N))
+        return zr;
     hipLaunchKernelGGL(project_max_bwd_kernel, dim3(hpcs_cdiv((int64_t)B * (C + Cc), 128)), dim3(128), 0, ST, x, xconst, z, arg,
                        gout, B, C, Cc, N, gx, gxconst, gz);
     HPCS_CHECK_LAUNCH();

@@ -41,7 +41,7 @@ def decode_linkage(x_poincare, loss, check=True):
     """Batch _decode_linkage: leaves = project(loss.normalize_embeddings(x)) then complete linkage on cosine."""
     from .distances.poincare import project
     with torch.no_grad():
-        leaves = project(loss.normalize_embeddings(x_poincare.detach()))
+        leaves = project(loss.normalize_rows(x_poincare.detach()))
     return complete_linkage(leaves, check=check)
 
 

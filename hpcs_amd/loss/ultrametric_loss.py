@@ -211,6 +211,8 @@ def class_metrics(logits, labels):
     counts = torch.empty(3 * C, dtype=torch.int64, device=logits.device)
     out = torch.empty(2, dtype=torch.float32, device=logits.device)
     call("hpcs_class_metrics", logits, labels.reshape(-1).to(torch.int64).contiguous(), M, C, counts, out)
+    if _lib.WATCH is not None and not _lib.WATCH.armed:          # diagnostics: watch the allocator block holding `out`
+        _lib.WATCH.arm(out.data_ptr() & ~511)
     return out[0], out[1]
 
 
@@ -375,13 +377,28 @@ class MetricHyperbolicLoss(torch.nn.Module):
         return TripletPlan(counts, self.t_per_anchor, self.fraction)
 
     def anneal_temperature(self):
-        self.temperature *= min(max(float(self.anneal_factor), 0.2), 1.0)
+        """temperature *= clamp(anneal_factor, 0.2, 1) (ultrametric_loss.py:133-137).  A TENSOR anneal_factor behaves exactly
+        like the reference (the temperature becomes a tensor; pinned by tests/golden/behaviour_r3.json).  DEVIATION, stated
+        in INTEGRATION.md: with a Python number -- the reference's own default, 0.5 -- the reference raises TypeError
+        (torch.clamp on a float), so `--anneal-step > 0` cannot run there; here the clamp is evaluated on the number."""
+        f = self.anneal_factor
+        if torch.is_tensor(f):
+            self.temperature = self.temperature * torch.clamp(f, 0.2, 1)
+        else:
+            self.temperature *= min(max(float(f), 0.2), 1.0)
         return self.temperature
 
     def normalize_embeddings(self, embeddings):
-        """Unit rows times clamp(scale, 1e-4, 1) (ultrametric_loss.py:139-143)."""
+        """F.normalize(embeddings, p=2, dim=1) * clamp(scale, 1e-4, 1) (ultrametric_loss.py:139-143); the reference only
+        ever passes [T, E] rows (:75-77)."""
+        if embeddings.dim() != 2:
+            raise ValueError("normalize_embeddings expects [T, E] rows (ultrametric_loss.py:75-77)")
+        return self.normalize_rows(embeddings)
+
+    def normalize_rows(self, embeddings):
+        """normalize_embeddings over the LAST dim of [..., E] (the batched decode path: one call for [B, N, E])."""
         s = self._scale_tensor(embeddings)
-        rows = embeddings.reshape(-1, embeddings.shape[-1])          # F.normalize(dim=-1) semantics for [.., E]
+        rows = embeddings.reshape(-1, embeddings.shape[-1])
         return (L2RowsFn.apply(rows) * torch.clamp(s, 1e-4, 1)).reshape(embeddings.shape)
 
 

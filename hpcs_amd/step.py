@@ -17,6 +17,17 @@ from .optim import RAdam
 FORWARD_SIDE = __import__("os").environ.get("HPCS_FWD_SIDE", "1") != "0"      # A/B: graph transposes in the forward pass
 
 
+def _watch_disarm(freeze=False):
+    """Diagnostics (hpcs_amd/_lib.py Watch): the watch armed by class_metrics ends with the step; a capture's call list is
+    kept (`freeze`) because replays execute exactly that list."""
+    from . import _lib
+    w = _lib.WATCH
+    if w is not None and w.armed:
+        w.disarm()
+        if freeze:
+            w.frozen = True
+
+
 def random_rotations(B, device, generator=None):
     """Haar-uniform SO(3) matrices [B,3,3] from normalised Gaussian quaternions, generated on the device
     (no host round trip: the reference's CPU rotation, shapenet_hyp_hc.py:63-69, is the step's only other host hop)."""
@@ -82,6 +93,7 @@ class HypHCStep(torch.nn.Module):
         self._rot_seed = None
         self._rot_calls = 0
         self.side_stream_wgrad = __import__("os").environ.get("HPCS_SIDE_STREAM", "1") != "0"   # 0: serial (profiling)
+        self.graph_serial_ok = __import__("os").environ.get("HPCS_GRAPH_SERIAL", "0") == "1"   # capture without the side stream
         # hipGraph replay of the steady-state step: HPCS_GRAPH = 1 (always), 0 (never) or auto (default: after the warm-up
         # the step is captured, two eager steps and two replays are timed with events, and the faster mode is kept --
         # replay wins when the step is launch-bound (small clouds: 2x at B=4, N=256), eager when it is GPU-bound and the
@@ -266,7 +278,7 @@ class HypHCStep(torch.nn.Module):
                 self.use_graph = False
         # (only the form with the weight-gradient side stream is replayed: the single-stream capture corrupts the returned
         # metric outputs after convergence, DESIGN.md "Round 2: ... weighed and not built")
-        return (self.use_graph and self.side_stream_wgrad and targets_host is not None and rot is None and drop_masks is None and loss.miner
+        return (self.use_graph and (self.side_stream_wgrad or self.graph_serial_ok) and targets_host is not None and rot is None and drop_masks is None and loss.miner
                 and loss.fused_filter and loss.hyp_miner.rng == "device" and loss.debug_triplets is None
                 and self.train_rotation in ("so3", None) and self.training)
 
@@ -349,6 +361,7 @@ class HypHCStep(torch.nn.Module):
         losses = self._backward_part(points, label, targets, ctx, rot, drop_masks)
         self.bucket.all_reduce_mean()
         self.optimizer.step(tables=ctx.radam_tables, tables_dev=ctx.radam_dev)
+        _watch_disarm()
         return losses
 
     def _graphed_step(self, points, label, targets, targets_host):
@@ -375,6 +388,7 @@ class HypHCStep(torch.nn.Module):
                 g["opt"] = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g["opt"], pool=g["pool"], capture_error_mode="thread_local"):
                     self.optimizer.step(tables=ctx.radam_tables, tables_dev=ctx.radam_dev)
+            _watch_disarm(freeze=True)
             self._graph = g
             # the capture itself executed nothing: fall through to the first replay with this step's parameters
         for dst, src in zip(g["in"], (points, label, targets)):

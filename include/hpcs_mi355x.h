@@ -424,6 +424,16 @@ int hpcs_optimal_k(const double* Z, const int64_t* y, int B, int N, int num_labe
 /* flat fp32 helpers used by the data-parallel wrapper (gradient bucket pack/unpack+scale) */
 int hpcs_scale_inplace(float* x, int64_t n, float s, hpcs_stream_t stream);
 
+/* ---- diagnostics (no reference counterpart): a stream-ordered watchpoint on a small device region ------------------
+ * hpcs_debug_snapshot copies `nbytes` (multiple of 4) of the watched region into a shadow buffer; hpcs_debug_watch
+ * compares region and shadow and records in status[0] the `seq` of the first call that saw them differ (status:
+ * int32[8], zeroed by the caller; [1] word offset, [2] found, [3] expected, [4] differing words, [5] next word,
+ * [6] checks so far, [7] [6] at the first mismatch).  hpcs_amd/_lib.py enqueues one watch after every launch when a
+ * watch is armed (HPCS_WATCH), also inside hipGraph captures; nothing is allocated. */
+int hpcs_debug_snapshot(const void* src, void* dst, int nbytes, hpcs_stream_t stream);
+int hpcs_debug_watch(const void* watched, const void* shadow, int nbytes, int seq, int32_t* status,
+                     hpcs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

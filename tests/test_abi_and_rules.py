@@ -153,3 +153,22 @@ def test_operator_api_signatures_match_reference():
         if why:
             problems.append(f"{key}: {why}\n      reference {ref_params}\n      ours      {got}")
     assert not problems, "\n".join(problems)
+
+
+def test_library_never_issues_memset_or_memcpy_nodes():
+    """Round 3 (DESIGN.md "The stray store"): memset NODES of a replayed hipGraph lose their arguments on this runtime once a
+    second graph exists (stale fill pattern / stale destination -> corrupted outputs, then a GPU memory-access fault).  The
+    library therefore zero-fills with its own kernel (csrc/common.h hpcs_zero_async) and must not call the runtime's
+    memset / memcpy entry points on the launch path."""
+    import re
+    csrc = os.path.join(ROOT, "hpcs_amd", "csrc")
+    pat = re.compile(r"\bhipMemset(Async|D8Async|D32Async)?\s*\(|\bhipMemcpy(Async|DtoDAsync|HtoDAsync|DtoHAsync)?\s*\(")
+    hits = []
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith((".hip", ".h")):
+            continue
+        for ln, line in enumerate(open(os.path.join(csrc, f)), 1):
+            code = line.split("//")[0]
+            if pat.search(code):
+                hits.append(f"{f}:{ln}: {line.strip()}")
+    assert hits == [], hits

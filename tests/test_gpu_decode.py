@@ -59,7 +59,7 @@ def test_decode_linkage_from_embeddings():
     scale = torch.nn.Parameter(torch.tensor([0.37], device=dev))
     loss = MetricHyperbolicLoss(scale=scale, num_class=4, embedding_size=16, cosface=True, miner=True).to(dev)
     x = (det_normalish((2, 192, 16), 77) * 0.3).to(dev)
-    leaves = project(loss.normalize_embeddings(x)).cpu().numpy()
+    leaves = project(loss.normalize_rows(x)).cpu().numpy()
     for b in range(2):
         np.testing.assert_allclose(leaves[b], OD.decode_leaves(x[b].cpu().numpy(), 0.37), rtol=2e-6, atol=1e-9)
     Z = decode.decode_linkage(x, loss).cpu().numpy()
@@ -139,7 +139,7 @@ def test_test_step_end_to_end():
     xp = out["x_poincare"]
     scale = float(step.scale.detach().cpu())
     from hpcs_amd.distances.poincare import project
-    leaves = project(step.metric_hyp_loss.normalize_embeddings(xp)).cpu().numpy()
+    leaves = project(step.metric_hyp_loss.normalize_rows(xp)).cpu().numpy()
     Z = out["linkage_matrix"].cpu().numpy()
     scores = []
     for b in range(B):
