@@ -307,6 +307,7 @@ def main():
         one_step()
         n_tune += 1
     mode = step.graph_mode() or "eager"
+    mode_label = f"graph captured {step.graph_variant()}" if mode == "graph" else mode
     barrier()
     timed = not args.no_kernel_timing
     # HIP events (on the launch stream) around every launch of the two heaviest kernels, live in the timed region:
@@ -381,8 +382,8 @@ def main():
         "config": {"workload": workload,
                    "global_batch": args.batch * world, "num_class": args.num_class,
                    "parallelism": f"dp{world} (per-replica BN and mining, one flat-gradient all-reduce)",
-                   "step_mode": f"{mode} (HPCS_GRAPH={os.environ.get('HPCS_GRAPH', 'auto')}"
-                                + (f"; measured ms/step replay vs eager: {step._tune['measured_ms']}"
+                   "step_mode": f"{mode_label} (HPCS_GRAPH={os.environ.get('HPCS_GRAPH', 'auto')}"
+                                + (f"; measured ms/step per candidate: {step._tune['measured_ms']}"
                                    if getattr(step, '_tune', None) and step._tune.get('measured_ms') else "") + ")",
                    "untimed_steps_before_the_timed_region": args.warmup + n_tune,
                    "triplet_rng": "device counter RNG (statistically equivalent to the reference's CPU torch.randint)",

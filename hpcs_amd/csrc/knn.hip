@@ -642,7 +642,11 @@ __global__ __launch_bounds__(64 * NW) void knn_mfma_bq_kernel(const float* __res
         double b1, b2;
         asm("v_min_f64 %0, %1, %2" : "=v"(b1) : "v"(lst[HI - 1]), "v"(p_j));
         asm("v_min_f64 %0, %1, %2" : "=v"(b2) : "v"(lst[HJ - 1]), "v"(p_i));
-        const double thr_key = knn_max(knn_max(lst[KK - 1], p_last), knn_max(b1, b2));
+        // k > KK (k = 33..40 on 32-wide lists): only bounds whose use the final merge can DETECT -- a key rejected below a
+        // list's own 32nd entry that belonged to the k best forces that list to run dry there (`redo`, repaired exactly);
+        // the cross-list bound has no such witness (16 + 16 better keys exhaust neither list while the key may rank 33..40)
+        double thr_key = knn_max(lst[KK - 1], p_last);
+        if (k <= KK) thr_key = knn_max(thr_key, knn_max(b1, b2));
         thr_f = knn_key_score(thr_key);
     };
 

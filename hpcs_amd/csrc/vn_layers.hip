@@ -537,10 +537,10 @@ __global__ void vn_apply_pool_fwd_kernel(PdRef pd, const float* __restrict__ mea
         }
     }
     float* op = out + ((b * Cout + c) * 3) * Np + n;
-    const float inv = 1.f / (float)pool_k;
-    op[0] = acc[0] * inv;
-    op[Np] = acc[1] * inv;
-    op[2 * Np] = acc[2] * inv;
+    const float kf = (float)pool_k;              // sum / k like torch's mean (a true division: x * (1/k) rounds twice)
+    op[0] = acc[0] / kf;
+    op[Np] = acc[1] / kf;
+    op[2 * Np] = acc[2] / kf;
 }
 
 // Tiled form of the fused mean_pool for the materialised layout with pool_k % 4 == 0, pool_k <= 64: a workgroup owns 64
@@ -605,10 +605,10 @@ __global__ __launch_bounds__(1024) void vn_apply_pool_tile_kernel(const float* _
             s2 += part[2][t * q4 + i];
         }
         float* op = out + (((int64_t)b * Cout + c) * 3) * Np + n0 + t;
-        const float inv = 1.f / (float)pool_k;
-        op[0] = s0 * inv;
-        op[Np] = s1 * inv;
-        op[2 * Np] = s2 * inv;
+        const float kf = (float)pool_k;          // sum / k like torch's mean
+        op[0] = s0 / kf;
+        op[Np] = s1 / kf;
+        op[2 * Np] = s2 / kf;
     }
 }
 
@@ -616,11 +616,11 @@ __device__ __forceinline__ void load_gout(const float* __restrict__ gout, int64_
                                           int pool_k, float (&g)[3]) {
     if (pool_k > 0) {
         const int64_t Np = L / pool_k;
-        const float inv = 1.f / (float)pool_k;
+        const float kf = (float)pool_k;          // MeanBackward: grad / k
         const float* gp = gout + ((b * Cout + c) * 3) * Np + l / pool_k;
-        g[0] = gp[0] * inv;
-        g[1] = gp[Np] * inv;
-        g[2] = gp[2 * Np] * inv;
+        g[0] = gp[0] / kf;
+        g[1] = gp[Np] / kf;
+        g[2] = gp[2 * Np] / kf;
     } else {
         load3(gout + ((b * Cout + c) * 3) * L + l, L, g);
     }
@@ -704,11 +704,11 @@ __global__ __launch_bounds__(TPB) void vn_bwd_reduce_vec_kernel(const float* __r
             }
             if (pool_k > 0) {
                 const int64_t Np = L / pool_k;
-                const float inv = 1.f / (float)pool_k;
+                const float kf = (float)pool_k;
                 const float* gp = gout + (((int64_t)b * Cout + c) * 3) * Np + l / pool_k;
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
-                    const float g = gp[a * Np] * inv;
+                    const float g = gp[a * Np] / kf;
                     gv[a][0] = g; gv[a][1] = g; gv[a][2] = g; gv[a][3] = g;
                 }
             } else {
@@ -1099,7 +1099,7 @@ __global__ __launch_bounds__(256) void vn_bwd_fused_kernel(
                 rd[a] = ok ? *reinterpret_cast<const float4*>(PD + (((int64_t)b * Ctot + Cout + ec) * 3 + a) * L + l) : z;
                 if (pool_k > 0) {
                     const int64_t Np = L / pool_k;
-                    const float gsc = ok ? gout[(((int64_t)b * Cout + ec) * 3 + a) * Np + l / pool_k] * (1.f / (float)pool_k) : 0.f;
+                    const float gsc = ok ? gout[(((int64_t)b * Cout + ec) * 3 + a) * Np + l / pool_k] / (float)pool_k : 0.f;
                     rg[a] = make_float4(gsc, gsc, gsc, gsc);         // pool_k % 4 == 0: the four positions share the point
                 } else {
                     rg[a] = ok ? *reinterpret_cast<const float4*>(gout + (((int64_t)b * Cout + ec) * 3 + a) * L + l) : z;

@@ -56,9 +56,7 @@ def rotate_to_channels_first(points, rot=None, seed=0, return_rot=False, seed_de
     return (x, R) if return_rot else x
 
 
-def to_categorical(y, num_classes):
-    """1-hot encode (hpcs/utils/data.py:24-29), on the device of y."""
-    return torch.nn.functional.one_hot(y.long(), num_classes).float()
+from .utils.data import to_categorical  # noqa: E402,F401  (hpcs/utils/data.py:24-29, on the device of y)
 
 
 class StepCtx:
@@ -93,7 +91,11 @@ class HypHCStep(torch.nn.Module):
         self._rot_seed = None
         self._rot_calls = 0
         self.side_stream_wgrad = __import__("os").environ.get("HPCS_SIDE_STREAM", "1") != "0"   # 0: serial (profiling)
-        self.graph_serial_ok = __import__("os").environ.get("HPCS_GRAPH_SERIAL", "0") == "1"   # capture without the side stream
+        # capture form of the replayed step: "side" (fork / join over the weight-gradient stream) or "serial" (one stream);
+        # auto mode measures both, HPCS_GRAPH=1 takes "side" unless HPCS_GRAPH_FORM / HPCS_SIDE_STREAM=0 say otherwise
+        forced_form = __import__("os").environ.get("HPCS_GRAPH_FORM", "").lower()
+        self._graph_form = forced_form if forced_form in ("side", "serial") else ("side" if self.side_stream_wgrad else "serial")
+        self._off_shape, self._off_shape_key = 0, None
         # hipGraph replay of the steady-state step: HPCS_GRAPH = 1 (always), 0 (never) or auto (default: after the warm-up
         # the step is captured, two eager steps and two replays are timed with events, and the faster mode is kept --
         # replay wins when the step is launch-bound (small clouds: 2x at B=4, N=256), eager when it is GPU-bound and the
@@ -276,18 +278,18 @@ class HypHCStep(torch.nn.Module):
             import torch.distributed as dist
             if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
                 self.use_graph = False
-        # (only the form with the weight-gradient side stream is replayed: the single-stream capture corrupts the returned
-        # metric outputs after convergence, DESIGN.md "Round 2: ... weighed and not built")
-        return (self.use_graph and (self.side_stream_wgrad or self.graph_serial_ok) and targets_host is not None and rot is None and drop_masks is None and loss.miner
+        return (self.use_graph and targets_host is not None and rot is None and drop_masks is None and loss.miner
                 and loss.fused_filter and loss.hyp_miner.rng == "device" and loss.debug_triplets is None
                 and self.train_rotation in ("so3", None) and self.training)
 
     def training_step(self, points, label, targets, targets_host=None, rot=None, drop_masks=None):
         """One optimisation step.  targets_host (CPU copy of the part labels) lets the miner's per-class plan be
         computed without a device->host sync in the middle of the step -- and makes the step replayable: after
-        `graph_warmup` eager steps the steady-state step is captured ONCE as a hipGraph (forward, losses, backward with
-        its side stream, RAdam; with more than one rank: two graphs around the eager all-reduce) and every later step
-        is: fill the parameter block (host, ~0.1 ms), one upload, one graph launch.  The losses returned by a replayed
+        `graph_warmup` eager steps the steady-state step is captured ONCE as a hipGraph (forward, losses, backward,
+        RAdam; with more than one rank: two graphs around the eager all-reduce) and every later step is: fill the
+        parameter block (host, ~0.1 ms), one upload, one graph launch.  Two capture forms exist -- "side" (the weight
+        gradients on their side stream: a fork / join graph) and "serial" (one stream: a linear graph, cheaper per node
+        for small clouds) -- and `HPCS_GRAPH=auto` times both against the eager step.  The losses returned by a replayed
         step are the capture's output tensors, overwritten by every replay."""
         if self._graph_eligible(targets_host, rot, drop_masks):
             if self._eager_steps >= self.graph_warmup:
@@ -303,31 +305,61 @@ class HypHCStep(torch.nn.Module):
         return self._eager_step(points, label, targets, targets_host, rot, drop_masks)
 
     def _auto_mode(self):
-        """auto mode schedule after the warm-up: capture + first replay (untimed), 2 timed replays, 2 timed eager steps,
-        then the faster mode for good.  Times are event spans of whole steps enqueued back to back.  (A third candidate, the
-        step captured WITHOUT its side stream, is 3 % faster on small clouds but corrupts the in-step metric outputs once
-        training has converged -- see DESIGN.md; it is not offered.)"""
+        """auto mode schedule after the warm-up, per candidate: capture + first replay (untimed), 2 timed replays -- first
+        the "side" form, then (that capture dropped: one private pool of activations at a time) the "serial" form -- then 2
+        timed eager steps; the fastest is kept for good (a winning "side" form is captured once more).  Times are event
+        spans of whole steps enqueued back to back.  The serial form was withdrawn in round 2 because its replays corrupted
+        the step's metric outputs; the cause was the runtime's handling of hipMemsetAsync NODES once a second graph exists
+        (DESIGN.md "The stray store"), and the library issues none any more."""
         t = self._tune
         if t is None:
-            t = self._tune = {"n": 0, "graph": [], "eager": [], "pending": None, "choice": None}
+            t = self._tune = {"n": 0, "graph_side": [], "graph_serial": [], "eager": [], "pending": None, "choice": None}
         if t["choice"] is not None:
             return t["choice"]
         self._collect_timing()
         t["n"] += 1
-        if t["n"] <= 3:
-            t["kind"] = "graph" if t["n"] > 1 else None            # replay 1 also pays the capture: not timed
+        forms = self._candidate_forms()
+        per = 3
+        if t["n"] <= per * len(forms):
+            k, j = divmod(t["n"] - 1, per)
+            if j == 0 and self._graph_form != forms[k]:
+                self._drop_graph()
+            self._graph_form = forms[k]
+            t["kind"] = f"graph_{forms[k]}" if j > 0 else None            # replay 1 also pays the capture: not timed
             return "graph"
-        if t["n"] <= 5:
+        if not self.use_graph:                                            # a capture failed: eager for good
+            t["choice"] = "eager"
+            return "eager"
+        if t["n"] <= per * len(forms) + 2:
             t["kind"] = "eager"
             return "eager_timed"
-        g, e = min(t["graph"]), min(t["eager"])
-        t["choice"] = "graph" if g <= e else "eager"
-        t["measured_ms"] = {"graph": g, "eager": e}
-        if t["choice"] == "eager":
+        ms = {f"graph_{f}": min(t[f"graph_{f}"]) for f in forms if t[f"graph_{f}"]}
+        ms["eager"] = min(t["eager"])
+        best = min(ms, key=ms.get)
+        t["measured_ms"] = ms
+        if best == "eager":
+            t["choice"] = "eager"
             self.use_graph = False
+            self._drop_graph()               # its private pool holds a whole step's activations: released for the eager winner
         else:
+            t["choice"] = "graph"
             self.graph_auto = False
+            form = best[len("graph_"):]
+            if form != self._graph_form:
+                self._drop_graph()
+                self._graph_form = form
         return t["choice"]
+
+    def _candidate_forms(self):
+        forced = __import__("os").environ.get("HPCS_GRAPH_FORM", "").lower()
+        if forced in ("side", "serial"):
+            return [forced]
+        return ["side", "serial"] if self.side_stream_wgrad else ["serial"]
+
+    def _drop_graph(self):
+        if self._graph is not None:
+            torch.cuda.synchronize()
+            self._graph = None
 
     def graph_mode(self):
         """'graph' / 'eager' once decided (or forced), else None while the auto mode is still measuring."""
@@ -336,6 +368,10 @@ class HypHCStep(torch.nn.Module):
         if not self.graph_auto:
             return "graph"
         return None if self._tune is None or self._tune["choice"] is None else self._tune["choice"]
+
+    def graph_variant(self):
+        """'side' | 'serial': how the replayed step is captured (meaningful while graph_mode() == 'graph')."""
+        return self._graph_form
 
     def _collect_timing(self):
         t = self._tune
@@ -355,29 +391,49 @@ class HypHCStep(torch.nn.Module):
         t["pending"] = (t.get("kind"), e0, e1)
         return out
 
+    # ---- host counters a step advances BEFORE its kernels run (restored when the step raises: ADVICE r2) -------------
+    def _counters(self):
+        loss, feat = self.metric_hyp_loss, self.nn_feat
+        return (self.optimizer.param_groups[0].get("step", 0), self._rot_calls,
+                loss.hyp_miner.seed if loss.miner else None, getattr(feat, "_drop_calls", None))
+
+    def _restore_counters(self, c):
+        loss, feat = self.metric_hyp_loss, self.nn_feat
+        self.optimizer.param_groups[0]["step"], self._rot_calls = c[0], c[1]
+        if c[2] is not None:
+            loss.hyp_miner.seed = c[2]
+        if c[3] is not None:
+            feat._drop_calls = c[3]
+
     def _eager_step(self, points, label, targets, targets_host, rot=None, drop_masks=None):
-        ctx = self._prepare(targets_host, own_rotation=(self.train_rotation == "so3" and rot is None),
-                            own_dropout=drop_masks is None)
+        saved = self._counters()
+        try:
+            ctx = self._prepare(targets_host, own_rotation=(self.train_rotation == "so3" and rot is None),
+                                own_dropout=drop_masks is None)
+            return self._run_eager(points, label, targets, ctx, rot, drop_masks)
+        except BaseException:
+            # RAdam's bias-correction count, the miner / rotation / dropout streams were advanced for a step that never
+            # applied (a caught OOM, a label check, a skipped batch): the reference only advances them inside a step that ran
+            self._restore_counters(saved)
+            raise
+
+    def _run_eager(self, points, label, targets, ctx, rot=None, drop_masks=None):
         losses = self._backward_part(points, label, targets, ctx, rot, drop_masks)
         self.bucket.all_reduce_mean()
         self.optimizer.step(tables=ctx.radam_tables, tables_dev=ctx.radam_dev)
         _watch_disarm()
         return losses
 
-    def _graphed_step(self, points, label, targets, targets_host):
+    def _capture(self, points, label, targets, ctx, shapes):
         import torch.distributed as dist
-        g = self._graph
-        shapes = (tuple(points.shape), tuple(label.shape), tuple(targets.shape), points.dtype, label.dtype, targets.dtype)
-        T_cap = g["T_cap"] if g is not None else 0
-        ctx = self._prepare(targets_host, own_rotation=self.train_rotation == "so3", own_dropout=True, T_cap=T_cap)
-        if g is not None and (g["shapes"] != shapes or ctx.plan.T > g["T_cap"]):
-            g = self._graph = None                           # geometry changed / more triplets than the grid covers
-        if g is None:
-            world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
-            g = {"shapes": shapes, "T_cap": int(ctx.plan.T * 1.25) + 1, "world": world,
-                 "in": (points.clone(), label.clone(), targets.clone())}
-            ctx.T_grid = g["T_cap"]
-            torch.cuda.synchronize()
+        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        g = {"shapes": shapes, "T_cap": int(ctx.plan.T * 1.25) + 1, "world": world, "form": self._graph_form,
+             "in": (points.clone(), label.clone(), targets.clone())}
+        ctx.T_grid = g["T_cap"]
+        torch.cuda.synchronize()
+        side = self.side_stream_wgrad
+        self.side_stream_wgrad = side and self._graph_form == "side"
+        try:
             g["fwd_bwd"] = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g["fwd_bwd"], capture_error_mode="thread_local"):
                 g["out"] = self._backward_part(*g["in"], ctx, None, None)
@@ -388,15 +444,55 @@ class HypHCStep(torch.nn.Module):
                 g["opt"] = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g["opt"], pool=g["pool"], capture_error_mode="thread_local"):
                     self.optimizer.step(tables=ctx.radam_tables, tables_dev=ctx.radam_dev)
+        finally:
+            self.side_stream_wgrad = side
             _watch_disarm(freeze=True)
-            self._graph = g
-            # the capture itself executed nothing: fall through to the first replay with this step's parameters
-        for dst, src in zip(g["in"], (points, label, targets)):
-            if dst.data_ptr() != src.data_ptr():
-                dst.copy_(src, non_blocking=True)
-        g["fwd_bwd"].replay()
-        if g["world"] > 1:
-            self.bucket.all_reduce_mean()
-            g["opt"].replay()
-        self.metric_hyp_loss.last_T = ctx.plan.T
-        return g["out"]
+        return g
+
+    def _graphed_step(self, points, label, targets, targets_host):
+        saved = self._counters()
+        try:
+            g = self._graph
+            shapes = (tuple(points.shape), tuple(label.shape), tuple(targets.shape), points.dtype, label.dtype, targets.dtype)
+            T_cap = g["T_cap"] if g is not None else 0
+            ctx = self._prepare(targets_host, own_rotation=self.train_rotation == "so3", own_dropout=True, T_cap=T_cap)
+            if ctx.plan.T == 0:
+                # nothing to sample (every class below two members): the loss takes its host-side path, not capturable
+                return self._run_eager(points, label, targets, ctx)
+            if g is not None and g["shapes"] != shapes:
+                # another geometry (a last partial batch): eager, keeping the capture; only a geometry that stays is captured
+                self._off_shape = self._off_shape + 1 if self._off_shape_key == shapes else 1
+                self._off_shape_key = shapes
+                if self._off_shape <= 3:
+                    ctx.T_grid = ctx.plan.T
+                    return self._run_eager(points, label, targets, ctx)
+                g = None
+            self._off_shape, self._off_shape_key = 0, None
+            if g is not None and (ctx.plan.T > g["T_cap"] or g["form"] != self._graph_form):
+                g = None                                         # more triplets than the grid covers / another form asked for
+            if g is None:
+                self._drop_graph()
+                try:
+                    g = self._graph = self._capture(points, label, targets, ctx, shapes)
+                except Exception as ex:                          # noqa: BLE001 -- any capture failure ends in the eager step
+                    import warnings
+                    warnings.warn(f"hpcs_amd: hipGraph capture of the training step failed ({type(ex).__name__}: {ex}); "
+                                  "continuing with the eager step")
+                    self._graph = None
+                    self.use_graph = False
+                    torch.cuda.synchronize()
+                    ctx.T_grid = ctx.plan.T
+                    return self._run_eager(points, label, targets, ctx)
+                # the capture itself executed nothing: fall through to the first replay with this step's parameters
+            for dst, src in zip(g["in"], (points, label, targets)):
+                if dst.data_ptr() != src.data_ptr():
+                    dst.copy_(src, non_blocking=True)
+            g["fwd_bwd"].replay()
+            if g["world"] > 1:
+                self.bucket.all_reduce_mean()
+                g["opt"].replay()
+            self.metric_hyp_loss.last_T = ctx.plan.T
+            return g["out"]
+        except BaseException:
+            self._restore_counters(saved)
+            raise

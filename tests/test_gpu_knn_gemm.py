@@ -80,6 +80,40 @@ def test_knn_k40_repair_pass_when_one_sublist_holds_all_neighbours(D):
     assert set(got[0, special[0]].tolist()) == set(special)          # the cluster's neighbours are the cluster
 
 
+def test_knn_k40_neighbours_split_over_both_lists_of_one_wave():
+    """k = 33..40 at D=3 runs the two-wave batch-queue kernel on 32-wide lists.  Its cross-list admission bound (a key with 16
+    better keys in each of the wave's two lists is out) is exact only for k <= 32: for k = 40 such a key can still rank
+    33..40 and neither list runs dry, so the repair pass never fires.  Adversarial cloud on a line: query 0's 40
+    nearest are 17 points in (wave 0, lane half 0), 17 in (wave 0, half 1), 5 in wave 1 -- and ONE point that arrives at a
+    late candidate tile of wave 0 with 17 + 17 better keys already listed and must still be returned (rank 38)."""
+    N, k = 2048, 40
+    xs = 1.0 + torch.arange(N, dtype=torch.float32) * 1e-3                 # everything far from the query by default
+    half0 = [p for p in range(32) if p % 8 < 4]
+    half1 = [p for p in range(32) if p % 8 >= 4]
+    near0 = half0 + [64]                                                   # tiles 0 and 2: wave 0 (even tiles), half 0
+    near1 = half1 + [68]
+    rank = 0
+    for a, b in zip(near0, near1):                                         # 34 near points, alternating between the lists
+        xs[a] = 1e-3 * rank
+        xs[b] = 1e-3 * (rank + 1)
+        rank += 2
+    wave1 = [32 + 1, 32 + 5, 96 + 2, 96 + 6, 160 + 3]                     # odd tiles: wave 1
+    for i, j in enumerate(wave1[:3]):
+        xs[j] = 0.040 + 1e-3 * i                                           # ranks 35..37
+    late = 60 * 32                                                         # tile 60 (wave 0), position 0 (half 0)
+    xs[late] = 0.045                                                       # rank 38
+    for i, j in enumerate(wave1[3:]):
+        xs[j] = 0.046 + 1e-3 * i                                           # ranks 39, 40
+    assert xs[0] == 0.0
+    x = torch.zeros(1, 3, N)
+    x[0, 0] = xs
+    want = OE.knn_exact(x, k)
+    assert late in want[0, 0].tolist() and want[0, 0].tolist().index(late) == 37
+    got = hip_knn(x, k)
+    assert late in got[0, 0].tolist()
+    assert torch.equal(got, want)
+
+
 def test_knn_duplicates_and_golden(golden):
     x = det_cloud(2, 128, 13, dup_every=5)
     assert torch.equal(hip_knn(x, 8), OE.knn_exact(x, 8))
