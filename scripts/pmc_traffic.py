@@ -6,14 +6,22 @@ bytes of wide (16 B/lane) coalesced streaming reads -> doubled for kernels whose
 (listed in WIDE); WRITE_SIZE is exact for 16 B/lane streaming stores and float atomics.  Other access widths are
 uncalibrated and are reported uncorrected (flagged).
 
-usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
+usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [steps in the profiled run]
 """
 import collections
 import csv
 import json
 import sys
 
-WIDE = ("gemm_tn_kernel", "gemm_nt_kernel")   # contiguous 16 B/lane staging loads
+# Kernels whose GLOBAL loads are contiguous 16 B/lane streaming reads (float4 / 128-bit staging loads; list made by scanning
+# csrc/*.hip for 16-byte global loads, r03): FETCH_SIZE counts half of their bytes.  r02 doubled the GEMMs only, which left the
+# vectorised element-wise passes under-counted (vn_bwd_apply reported 183 MB fetched where it reads a 330 MB PD + 165 MB g).
+WIDE = ("gemm_tn_kernel", "gemm_nt_kernel", "gemm_nt_edge_kernel", "_vec_kernel", "vn_bwd_apply_kernel",
+        "vn_apply_pool_fwd_kernel", "vn_apply_pool_tile_kernel", "k2all_kernel", "edge_gather_bwd_center",
+        "edge_segsum_kernel", "edge_gather_bwd_inv_kernel", "edge_grad_reduce_inv_kernel", "edge_grad_reduce_slab_kernel",
+        "rowsum_wave_kernel", "rowsum_long_kernel", "vn_bwd_fused_kernel", "hpcs_zero_kernel")
+# 16 B/lane row GATHERS (random rows through L2): the x2 rule is calibrated for streaming reads only -> reported uncorrected
+GATHER = ("hyphc_sampled_kernel", "hyphc_kernel", "knn_mfma", "edge_gather_fwd_kernel")
 
 
 def per_kernel(path, counter):
@@ -46,9 +54,15 @@ def main():
         wb = w * 1024
         n = max(nf, nw, 1)
         out[short(name)] = {"launches": n, "fetch_bytes_per_launch": round(fb / n), "write_bytes_per_launch": round(wb / n),
-                            "hbm_bytes_per_launch": round((fb + wb) / n), "fetch_x2_correction": wide}
+                            "hbm_bytes_per_launch": round((fb + wb) / n), "fetch_x2_correction": wide,
+                            "fetch_uncalibrated_gather": any(t in name for t in GATHER)}
+    steps = int(sys.argv[4]) if len(sys.argv) > 4 else None
+    total = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in out.values())
+    out["_total"] = {"hbm_bytes_all_launches": total, "steps_in_run": steps,
+                     "hbm_bytes_per_step": round(total / steps) if steps else None,
+                     "note": "FETCH_SIZE doubled for the kernels in WIDE (16 B/lane streaming reads); gathers uncorrected"}
     json.dump(out, open(sys.argv[3], "w"), indent=1)
-    for k, v in list(out.items())[:14]:
+    for k, v in [kv for kv in out.items() if kv[0] != "_total"][:14]:
         print(f"{v['hbm_bytes_per_launch'] / 1e6:10.1f} MB/launch  x{v['launches']:4d}  {k}")
 
 

@@ -32,12 +32,8 @@ from oracle import extractor as OE  # noqa: E402  (checker only)
 import test_gpu_round2 as R2  # noqa: E402  (_Tap, _oracle_eval, relerr)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--seeds", type=int, default=8)
-    ap.add_argument("--E", type=int, default=32)
-    ap.add_argument("--mode", default="train")
-    a = ap.parse_args()
+def run(seeds=12, E=32, mode="train", verbose=True):
+    a = argparse.Namespace(seeds=seeds, E=E, mode=mode)
     from hpcs_amd.nn.dgcnn import VN_DGCNN_partseg
     dev = "cuda"
     torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 16)))
@@ -74,8 +70,9 @@ def main():
         for vn, tensors in variants.items():
             row[vn] = {nm: R2.relerr(tensors[nm], a64[nm]) for nm in names}
         runs.append(row)
-        print(f"[ensemble] seed {s}: out L2 hip {row['hip']['out'][1]:.2e} cpu {row['torch_cpu_fp32']['out'][1]:.2e} "
-              f"gpu {row['torch_gpu_fp32']['out'][1]:.2e}", file=sys.stderr, flush=True)
+        if verbose:
+            print(f"[ensemble] seed {s}: out L2 hip {row['hip']['out'][1]:.2e} cpu {row['torch_cpu_fp32']['out'][1]:.2e} "
+                  f"gpu {row['torch_gpu_fp32']['out'][1]:.2e}", file=sys.stderr, flush=True)
 
     def med(v):
         v = sorted(v)
@@ -97,8 +94,17 @@ def main():
                 "gmean_ratio_gpu_over_cpu": gmean([x_ / y_ for x_, y_ in zip(g, c)]),
                 "worst_ratio_hip_over_max_of_both": max(x_ / max(y_, z_) for x_, y_, z_ in zip(h, c, g)),
                 "min_max_hip": [min(h), max(h)], "min_max_cpu": [min(c), max(c)], "min_max_gpu": [min(g), max(g)]}
-    print(json.dumps({"geometry": "[4,3,256], k=10, E=%d, %s mode, dropout 0, fp64 graphs injected" % (a.E, a.mode),
-                      "seeds": a.seeds, "summary": summary, "runs": runs}, indent=1))
+    return {"geometry": "[4,3,256], k=10, E=%d, %s mode, dropout 0, fp64 graphs injected" % (a.E, a.mode),
+            "seeds": a.seeds, "summary": summary, "runs": runs}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seeds", type=int, default=12)
+    ap.add_argument("--E", type=int, default=32)
+    ap.add_argument("--mode", default="train")
+    a = ap.parse_args()
+    print(json.dumps(run(a.seeds, a.E, a.mode), indent=1))
 
 
 if __name__ == "__main__":

