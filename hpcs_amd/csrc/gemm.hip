@@ -327,12 +327,103 @@ __global__ __launch_bounds__(256) void gemm_tn_small_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// In-launch split reduction of the weight-gradient GEMMs (r03; replaces the split_reduce_kernel launches that followed
+// every hpcs_gemm_nt: 26 per training step, 1.0 ms of side-stream time).  Every split workgroup publishes its partial tile
+// and takes a ticket; the last arriver of a SLICE of splits sums that slice's partials in split order, and -- two levels,
+// when a tile has many splits (the EdgeConv gradients: one 42 x 42 tile over ~1900 splits) -- the last slice-reducer sums
+// the slice partials in slice order into dW.  Fixed summation order: bit-reproducible.
+// Visibility (per-XCD L2s are not coherent, MI355X_MICROARCH "inter-workgroup visibility"): the partials are stored
+// WRITE-THROUGH (agent-scope relaxed atomic stores = `global_store_dword sc1`), every storing wave drains `vmcnt(0)`, the
+// workgroup meets at a barrier, ONE lane adds to the ticket (agent-scope atomic), and the reducer reads every partial with
+// `sc1` loads.  No release / acquire fence: `buffer_wbl2` would write back the whole XCD L2, i.e. the main stream's
+// 330 MB gradient tensors in flight beside these side-stream GEMMs.  Tickets come zeroed from the caller (the step's
+// fp64 arena: one fill per step); the last reducer leaves them zero again.
+struct NtFuse {
+    unsigned* tickets;        // [tiles * (slices + 1)]: per (tile, slice) arrivals, then per tile slice arrivals; nullptr: off
+    float* stage;             // [slices][M * Kx] slice sums (two-level only)
+    float* dW;
+    int lddw, accumulate, slice_len, slices;
+};
+__device__ __forceinline__ void nt_store_wt(float* p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float nt_load_wt(const float* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Called by EVERY thread of the workgroup after its partial stores.  `sh` is one int of LDS.  Tile = rows [m0, m0 + BMt) x
+// columns [x0, x0 + BNt) of the M x Kx result; `split` is this workgroup's split index, `tile` its tile index.
+template <int NT>
+__device__ __forceinline__ void nt_fused_reduce(const NtFuse& f, const float* __restrict__ part, int nsplit, int split, int tile,
+                                                int tiles, int M, int Kx, int m0, int x0, int BMt, int BNt, int* sh) {
+    const int tid = threadIdx.x;
+    const int64_t ne = (int64_t)M * Kx;
+    const int slice = split / f.slice_len;
+    const int s0 = slice * f.slice_len, s1 = min(nsplit, s0 + f.slice_len);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's write-through partial stores have been performed
+    __syncthreads();
+    if (tid == 0)
+        *sh = __hip_atomic_fetch_add(f.tickets + (int64_t)tile * f.slices + slice, 1u, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(s1 - s0 - 1);
+    __syncthreads();
+    if (!*sh) return;
+    const bool two = f.slices > 1;
+    // level 1: sum the slice's partials in split order (8 independent loads in flight per element)
+    for (int e = tid; e < BMt * BNt; e += NT) {
+        const int row = m0 + e / BNt, col = x0 + e % BNt;
+        if (row >= M || col >= Kx) continue;
+        const int64_t o = (int64_t)row * Kx + col;
+        float acc = 0.f;
+        int sp = s0;
+        for (; sp + 8 <= s1; sp += 8) {
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = nt_load_wt(part + (int64_t)(sp + q) * ne + o);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc += v[q];
+        }
+        for (; sp < s1; ++sp) acc += nt_load_wt(part + (int64_t)sp * ne + o);
+        if (two) {
+            nt_store_wt(f.stage + (int64_t)slice * ne + o, acc);
+        } else {
+            float* d = f.dW + (int64_t)row * f.lddw + col;
+            *d = f.accumulate ? *d + acc : acc;
+        }
+    }
+    if (tid == 0) __hip_atomic_store(f.tickets + (int64_t)tile * f.slices + slice, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!two) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0)
+        *sh = __hip_atomic_fetch_add(f.tickets + (int64_t)tiles * f.slices + tile, 1u, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(f.slices - 1);
+    __syncthreads();
+    if (!*sh) return;
+    for (int e = tid; e < BMt * BNt; e += NT) {
+        const int row = m0 + e / BNt, col = x0 + e % BNt;
+        if (row >= M || col >= Kx) continue;
+        const int64_t o = (int64_t)row * Kx + col;
+        float acc = 0.f;
+        int sl = 0;
+        for (; sl + 8 <= f.slices; sl += 8) {
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = nt_load_wt(f.stage + (int64_t)(sl + q) * ne + o);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc += v[q];
+        }
+        for (; sl < f.slices; ++sl) acc += nt_load_wt(f.stage + (int64_t)sl * ne + o);
+        float* d = f.dW + (int64_t)row * f.lddw + col;
+        *d = f.accumulate ? *d + acc : acc;
+    }
+    if (tid == 0) __hip_atomic_store(f.tickets + (int64_t)tiles * f.slices + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // weight-grad: both operands have the reduction index (columns) contiguous.
 template <int BM, int BN, int BKC, int WM, int WN>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(
     const float* __restrict__ G, int ldg, int64_t sGo, int64_t sGi, const float* __restrict__ X, int ldx,
     int64_t sXo, int64_t sXi, int M, int Kx, int Nc, int n_inner, int n_batch, int chunk, int units_per_batch,
-    int nsplit, float* __restrict__ part, int tilesM, int tilesK, int vecG, int vecX) {
+    int nsplit, float* __restrict__ part, int tilesM, int tilesK, int vecG, int vecX, NtFuse fuse) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     // Row pitch BKC + 4 floats: rows start on 16 bytes, so staging is one ds_write_b128 per float4 and the MFMA operands
@@ -453,6 +544,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(
         }
     }
     float* P = part + (int64_t)split * M * Kx;
+    const bool fused = fuse.tickets != nullptr;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -461,9 +553,16 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                if (row < M && col < Kx) P[(int64_t)row * Kx + col] = acc[i][j][r];
+                if (row < M && col < Kx) {
+                    if (fused) nt_store_wt(P + (int64_t)row * Kx + col, acc[i][j][r]);
+                    else P[(int64_t)row * Kx + col] = acc[i][j][r];
+                }
             }
         }
+    if (fused) {
+        __syncthreads();                                   // the operand tiles are dead: their first word serves as the flag
+        nt_fused_reduce<NT>(fuse, part, nsplit, split, tile, tilesM * tilesK, M, Kx, m0, x0, BM, BN, reinterpret_cast<int*>(&Gs[0][0]));
+    }
 }
 
 // EdgeConv weight gradients: one output tile with M, Kx <= 48 over millions of columns.  On the 64x64 tile of the
@@ -475,7 +574,7 @@ constexpr int NE_T = 48;
 __global__ __launch_bounds__(256) void gemm_nt_edge_kernel(
     const float* __restrict__ G, int ldg, int64_t sGo, int64_t sGi, const float* __restrict__ X, int ldx,
     int64_t sXo, int64_t sXi, int M, int Kx, int Nc, int n_inner, int n_batch, int chunk, int units_per_batch,
-    int nsplit, float* __restrict__ part, int vecG, int vecX) {
+    int nsplit, float* __restrict__ part, int vecG, int vecX, NtFuse fuse) {
     constexpr int BKC = 32, NT = 256, LD = BKC + 4;          // pitch 36: 16-byte row starts (ds_write_b128), operand fetch
                                                              // (16 rows x 4 columns per instruction) spreads over all banks
     constexpr int NLD = NE_T * (BKC / 4);                    // 384 float4 per operand tile
@@ -574,7 +673,13 @@ __global__ __launch_bounds__(256) void gemm_nt_edge_kernel(
     }
     __syncthreads();
     float* P = part + (int64_t)split * M * Kx;
-    for (int e = tid; e < M * Kx; e += NT) P[e] = tile[(e / Kx) * NE_T + e % Kx];
+    if (fuse.tickets == nullptr) {
+        for (int e = tid; e < M * Kx; e += NT) P[e] = tile[(e / Kx) * NE_T + e % Kx];
+        return;
+    }
+    for (int e = tid; e < M * Kx; e += NT) nt_store_wt(P + e, tile[(e / Kx) * NE_T + e % Kx]);
+    __syncthreads();                                       // the staged tile has been read: its first word serves as the flag
+    nt_fused_reduce<NT>(fuse, part, nsplit, split, 0, 1, M, Kx, 0, 0, NE_T, NE_T, reinterpret_cast<int*>(tile));
 }
 
 // Sums the split partials in a FIXED order (deterministic).  64 outputs per workgroup, 16 waves each own every
@@ -785,9 +890,20 @@ extern "C" size_t hpcs_gemm_nt_workspace(int M, int Kx, int Nc, int n_outer, int
     return ((size_t)p.nsplit * M * Kx + stage) * sizeof(float);
 }
 
-extern "C" int hpcs_gemm_nt(const float* G, int ldg, int64_t strideG_o, int64_t strideG_i, const float* X, int ldx,
-                            int64_t strideX_o, int64_t strideX_i, int M, int Kx, int Nc, int n_outer, int n_inner,
-                            float* dW, int lddw, int accumulate, void* ws, size_t ws_bytes, hpcs_stream_t stream) {
+// number of 32-bit tickets hpcs_gemm_nt_fused needs (zeroed by the caller before the FIRST use; left zero by every call)
+extern "C" size_t hpcs_gemm_nt_tickets(int M, int Kx, int Nc, int n_outer, int n_inner) {
+    if (M <= 0 || Kx <= 0 || Nc <= 0 || n_outer <= 0 || n_inner <= 0) return 0;
+    const NtPlan p = nt_plan(M, Kx, Nc, n_outer * n_inner);
+    const bool two = sr_two_level(p.nsplit, (int64_t)M * Kx);
+    const int slice_len = two ? hpcs_cdiv(p.nsplit, SR_SLICES) : p.nsplit;
+    const int slices = hpcs_cdiv(p.nsplit, slice_len);
+    return (size_t)p.tilesM * p.tilesK * (slices + 1);
+}
+
+static int gemm_nt_impl(const float* G, int ldg, int64_t strideG_o, int64_t strideG_i, const float* X, int ldx,
+                        int64_t strideX_o, int64_t strideX_i, int M, int Kx, int Nc, int n_outer, int n_inner,
+                        float* dW, int lddw, int accumulate, void* ws, size_t ws_bytes, unsigned* tickets, size_t n_tickets,
+                        hpcs_stream_t stream) {
     if (!G || !X || !dW || !ws) return HPCS_ERR_NULL;
     if (M <= 0 || Kx <= 0 || Nc <= 0 || n_outer <= 0 || n_inner <= 0 || ldg < Nc || ldx < Nc || lddw < Kx)
         return HPCS_ERR_SHAPE;
@@ -800,23 +916,30 @@ extern "C" int hpcs_gemm_nt(const float* G, int ldg, int64_t strideG_o, int64_t 
     const int vecG = (ldg % 4 == 0) && (strideG_o % 4 == 0) && (strideG_i % 4 == 0) && aligned16(G);
     const int vecX = (ldx % 4 == 0) && (strideX_o % 4 == 0) && (strideX_i % 4 == 0) && aligned16(X);
     const long blocks = (long)p.tilesM * p.tilesK * p.nsplit;
+    const int64_t ne = (int64_t)M * Kx;
+    const int slice_len = two_level ? hpcs_cdiv(p.nsplit, SR_SLICES) : p.nsplit;
+    const int slices = hpcs_cdiv(p.nsplit, slice_len);
+    float* stage = (float*)ws + (size_t)p.nsplit * ne;
+    NtFuse fuse{nullptr, stage, dW, lddw, accumulate, slice_len, slices};
+    if (tickets) {
+        if (n_tickets < (size_t)p.tilesM * p.tilesK * (slices + 1)) return HPCS_ERR_WORKSPACE;
+        fuse.tickets = tickets;
+    }
     if (p.tilesM * p.tilesK == 1 && M <= NE_T && Kx <= NE_T)
         hipLaunchKernelGGL(gemm_nt_edge_kernel, dim3((unsigned)blocks), dim3(256), 0, st, G, ldg, strideG_o, strideG_i, X, ldx,
                            strideX_o, strideX_i, M, Kx, Nc, n_inner, nb, p.chunk, p.units_per_batch, p.nsplit, (float*)ws, vecG,
-                           vecX);
+                           vecX, fuse);
     else if (p.tile == 128)
         hipLaunchKernelGGL((gemm_nt_kernel<128, 128, NT_BKC, 2, 2>), dim3((unsigned)blocks), dim3(256), 0, st, G, ldg,
                            strideG_o, strideG_i, X, ldx, strideX_o, strideX_i, M, Kx, Nc, n_inner, nb, p.chunk,
-                           p.units_per_batch, p.nsplit, (float*)ws, p.tilesM, p.tilesK, vecG, vecX);
+                           p.units_per_batch, p.nsplit, (float*)ws, p.tilesM, p.tilesK, vecG, vecX, fuse);
     else
         hipLaunchKernelGGL((gemm_nt_kernel<64, 64, NT_BKC, 2, 2>), dim3((unsigned)blocks), dim3(256), 0, st, G, ldg,
                            strideG_o, strideG_i, X, ldx, strideX_o, strideX_i, M, Kx, Nc, n_inner, nb, p.chunk,
-                           p.units_per_batch, p.nsplit, (float*)ws, p.tilesM, p.tilesK, vecG, vecX);
+                           p.units_per_batch, p.nsplit, (float*)ws, p.tilesM, p.tilesK, vecG, vecX, fuse);
     HPCS_CHECK_LAUNCH();
-    const int64_t ne = (int64_t)M * Kx;
+    if (fuse.tickets) return HPCS_OK;
     if (two_level) {
-        float* stage = (float*)ws + (size_t)p.nsplit * ne;
-        const int slice_len = hpcs_cdiv(p.nsplit, SR_SLICES), slices = hpcs_cdiv(p.nsplit, slice_len);
         hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)hpcs_cdiv(ne, 64), (unsigned)slices), dim3(1024), 0, st,
                            (const float*)ws, p.nsplit, slice_len, M, Kx, dW, lddw, 0, stage);
         HPCS_CHECK_LAUNCH();
@@ -828,6 +951,22 @@ extern "C" int hpcs_gemm_nt(const float* G, int ldg, int64_t strideG_o, int64_t 
     }
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;
+}
+
+extern "C" int hpcs_gemm_nt(const float* G, int ldg, int64_t strideG_o, int64_t strideG_i, const float* X, int ldx,
+                            int64_t strideX_o, int64_t strideX_i, int M, int Kx, int Nc, int n_outer, int n_inner,
+                            float* dW, int lddw, int accumulate, void* ws, size_t ws_bytes, hpcs_stream_t stream) {
+    return gemm_nt_impl(G, ldg, strideG_o, strideG_i, X, ldx, strideX_o, strideX_i, M, Kx, Nc, n_outer, n_inner, dW, lddw,
+                        accumulate, ws, ws_bytes, nullptr, 0, stream);
+}
+
+extern "C" int hpcs_gemm_nt_fused(const float* G, int ldg, int64_t strideG_o, int64_t strideG_i, const float* X, int ldx,
+                                  int64_t strideX_o, int64_t strideX_i, int M, int Kx, int Nc, int n_outer, int n_inner,
+                                  float* dW, int lddw, int accumulate, void* ws, size_t ws_bytes, int32_t* tickets,
+                                  size_t n_tickets, hpcs_stream_t stream) {
+    if (!tickets) return HPCS_ERR_NULL;
+    return gemm_nt_impl(G, ldg, strideG_o, strideG_i, X, ldx, strideX_o, strideX_i, M, Kx, Nc, n_outer, n_inner, dW, lddw,
+                        accumulate, ws, ws_bytes, (unsigned*)tickets, n_tickets, stream);
 }
 
 extern "C" int hpcs_prep_weights(const float* W1, int ld1, int M1, const float* W2, int ld2, int M2, int K, float* At, int lda,

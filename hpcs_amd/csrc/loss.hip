@@ -920,6 +920,258 @@ __global__ __launch_bounds__(SB_THREADS) void hyphc_sampled_kernel(
     }
 }
 
+template <int EPL, bool GRAD>
+__global__ __launch_bounds__(SB_THREADS) void hyphc_sampled4_kernel(
+    const float* __restrict__ xn, const int64_t* __restrict__ labels, const int32_t* __restrict__ order,
+    const int32_t* __restrict__ offsets, const int64_t* __restrict__ cls_toff, const int32_t* __restrict__ cls_k, int C,
+    int M, int64_t T_arg, uint64_t seed, const uint64_t* __restrict__ seed_dev, const float* __restrict__ scale,
+    float temperature, float margin, int kind, int RC,
+    double* __restrict__ loss_sum, unsigned long long* __restrict__ kept_out, float* __restrict__ gxn,
+    double* __restrict__ gscale, int64_t* __restrict__ a_dbg, int64_t* __restrict__ p_dbg, int64_t* __restrict__ n_dbg,
+    unsigned perm_mul, int seg_len) {
+    constexpr int E = 8 * EPL;
+    using IO = RowIO<EPL, true>;
+    constexpr int LD = E + 8;
+    // positive table: row stride TS = E + 8 and element (lane s, j) at j*8 + s, so one ds_add_f32 wave-instruction
+    // (8 groups x 8 lanes, same j) spreads over the banks instead of stacking 8 deep on every fourth one
+    constexpr int TS = E + 8;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* cache = smem;                                            // [RC][TS]  (GRAD only)
+    float* stage = smem + (GRAD ? (size_t)RC * TS : 0);             // [waves][16][LD] negative-row ring + [waves][16] row ids
+    __shared__ double red[16];
+    __shared__ int cb_sh[3];
+
+    // The number of sampled triplets is the plan's last prefix entry; T_arg only sized the grid (>= T: a replayed graph
+    // keeps the grid of the largest batch seen so far, surplus workgroups fall through the bounds tests below).
+    // 32-bit triplet counters (the launcher sends T >= 2^31 - 2^24 to the r02 kernel): six registers at the 128 cap
+    const int T = (int)cls_toff[C];
+    (void)T_arg;
+    if (seed_dev) seed = *seed_dev;
+    const float sraw = *scale;
+    const float sc = fminf(fmaxf(sraw, 1e-4f), 1.f);
+    const bool s_live = sraw >= 1e-4f && sraw <= 1.f;
+    const float inv_t = 1.f / temperature;
+    const unsigned seed_lo = (unsigned)seed, seed_hi = (unsigned)(seed >> 32);
+    const int lane = threadIdx.x & 63;
+    const int s = threadIdx.x % SUB, g = threadIdx.x / SUB;
+    const int sub0 = lane & ~(SUB - 1);
+    const unsigned pblock = (unsigned)(((uint64_t)blockIdx.x * perm_mul) % gridDim.x);
+    const int block_base = (int)(pblock * (unsigned)(SB_GROUPS * seg_len));
+    if (block_base >= T) return;             // surplus workgroup of a grid sized for a larger batch (uniform per block)
+
+    if (threadIdx.x == 0) {
+        const int cb = class_of(cls_toff, C, block_base < T ? block_base : T - 1);
+        cb_sh[0] = cb;
+        cb_sh[1] = offsets[cb];
+        cb_sh[2] = offsets[cb + 1] - offsets[cb];
+    }
+    if (GRAD)
+        for (int i = threadIdx.x; i < RC * TS; i += SB_THREADS) cache[i] = 0.f;
+    __syncthreads();
+    const int cb = cb_sh[0];
+
+    const int seg = block_base + g * seg_len;
+    // lane-private class cursor (all 8 lanes of a group are within a few triplets of each other)
+    int c = class_of(cls_toff, C, seg < T ? seg : T - 1);
+    int c_t0 = (int)cls_toff[c], c_t1 = (int)cls_toff[c + 1];
+    int c_k = cls_k[c], c_off = offsets[c], c_na = offsets[c + 1] - c_off;
+    double acc_loss = 0.0, acc_gs = 0.0;
+    unsigned kept = 0;
+    float acc_a[EPL];
+    int cur = -1;
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) acc_a[j] = 0.f;
+
+    // wave-private ring of pending negative-row gradients (GRAD only)
+    float* qrows = stage + (threadIdx.x >> 6) * (16 * LD);
+    int* qid = reinterpret_cast<int*>(stage + (SB_THREADS / 64) * (16 * LD)) + (threadIdx.x >> 6) * 16;
+    int qh = 0, qn = 0;
+    // r03: FOUR triplets per 8-lane group and batch (lanes s and s + 4 generate the same triplet).  The rows of a batch --
+    // four positive and four negative rows, 32 registers -- are requested together and STAY in registers through the
+    // scalar phase, so the gradient phase gathers nothing a second time (round 2's kernel walked its 8 triplets twice and
+    // fetched every kept triplet's rows again through L2: 0.67 ms of 2.06 at 50 % kept); the price is the per-triplet scalar
+    // math (three LCA distances, softmax) evaluated by two lanes instead of one.
+    int ia_have = -1;                                                   // anchor whose row sits in av
+    float av[EPL];
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) av[j] = 0.f;
+    const bool owner = s < 4;                                           // lanes 4..7 shadow lanes 0..3
+    for (int b4 = 0; b4 < seg_len / 4; ++b4) {
+        const int tl = seg + b4 * 4 + (s & 3);
+        const bool lv_own = tl < T;
+        const int tt = lv_own ? tl : T - 1;
+        while (tt >= c_t1 && c + 1 < C) {
+            ++c;
+            c_t0 = c_t1;
+            c_t1 = (int)cls_toff[c + 1];
+            if (c_t1 > c_t0) { c_k = cls_k[c]; c_off = offsets[c]; c_na = offsets[c + 1] - c_off; }
+        }
+        const unsigned kq = (unsigned)(c_k > 0 ? c_k : 1);
+        const int rank = (int)((unsigned)(tt - c_t0) / kq);
+        const int ia_own = order[c_off + rank];
+        const unsigned hp = hash32((unsigned)tt ^ seed_lo, seed_hi);          // (tt >> 32) == 0: the r02 kernel's stream
+        const int rp = (int)__umulhi(hp, (unsigned)(c_na > 1 ? c_na - 1 : 1));
+        const int pr_own = rp + (rp >= rank ? 1 : 0);
+        const int ip_own = order[c_off + (pr_own < c_na ? pr_own : 0)];
+        int in_own;
+        {
+            const unsigned h = hash32(hp ^ 0x9E3779B9u, (unsigned)tt + seed_hi);
+            const int n_other = M - c_na;
+            const int rn = (int)__umulhi(h, (unsigned)(n_other > 0 ? n_other : 1));
+            const int slot = rn + (rn >= c_off ? c_na : 0);
+            in_own = order[slot < M ? slot : M - 1];
+        }
+        if (a_dbg && lv_own && owner) { a_dbg[tl] = ia_own; p_dbg[tl] = ip_own; n_dbg[tl] = in_own; }
+        const int cpos_own = (c == cb && pr_own < RC) ? pr_own : -1;       // slot in the LDS positive table, or -1
+
+        // ---- phase A: all eight rows of the batch in flight at once; three dot products per triplet
+        float P[4][EPL], Ng[4][EPL];
+        // (indices are re-broadcast where they are needed -- two DPP moves -- instead of living in 12 registers across the
+        // scalar phase: the kernel sits at the 128-register cap of four waves per SIMD)
+#define BQ(v, q) ((q) == 0 ? grp_bcast<0>(v) : (q) == 1 ? grp_bcast<1>(v) : (q) == 2 ? grp_bcast<2>(v) : grp_bcast<3>(v))
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            IO::load(xn, E, BQ(ip_own, q), s, P[q]);
+            IO::load(xn, E, BQ(in_own, q), s, Ng[q]);
+        }
+        float D1 = 0.f, D2 = 0.f, D3 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ia_q = BQ(ia_own, q);
+            if (ia_q != ia_have) {                                      // the anchor changes once per ~k_c triplets
+                IO::load(xn, E, ia_q, s, av);
+                ia_have = ia_q;
+            }
+            float d1 = 0.f, d2 = 0.f, d3 = 0.f;
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+                d1 += av[j] * P[q][j];
+                d2 += av[j] * Ng[q][j];
+                d3 += P[q][j] * Ng[q][j];
+            }
+            d1 = grp_sum(d1);
+            d2 = grp_sum(d2);
+            d3 = grp_sum(d3);
+            const bool mine = (s & 3) == q;
+            D1 = mine ? d1 : D1;
+            D2 = mine ? d2 : D2;
+            D3 = mine ? d3 : D3;
+        }
+        // ---- phase B: the scalar part of this lane's triplet (three LCA distances, the softmax, the weights)
+        bool live = lv_own;
+        if (kind >= 0) live = live && keep_rule(0.5f * (1.f + D1) - 0.5f * (1.f + D2), margin, kind);
+        if (live && owner) ++kept;
+        const LcaF L1 = lca_of_dot(sc, D1), L2 = lca_of_dot(sc, D2), L3 = lca_of_dot(sc, D3);
+        const float q0 = L1.d * inv_t, q1 = L2.d * inv_t, q2 = L3.d * inv_t;
+        const float mx = fmaxf(q0, fmaxf(q1, q2));
+        const float e0 = __expf(q0 - mx), e1 = __expf(q1 - mx), e2 = __expf(q2 - mx);
+        const float w0 = 0.5f * (1.f + D1), w1 = 0.5f * (1.f + D2), w2 = 0.5f * (1.f + D3);
+        const float den = e0 + e1 + e2;
+        const float wbar = (e0 * w0 + e1 * w1 + e2 * w2) / den;
+        if (live && owner) acc_loss += (double)((w0 + w1 + w2) - wbar);
+        if (GRAD) {
+            const float sm0 = e0 / den, sm1 = e1 / den, sm2 = e2 / den;
+            const float gd0 = -(sm0 * (w0 - wbar)) * inv_t, gd1 = -(sm1 * (w1 - wbar)) * inv_t,
+                        gd2 = -(sm2 * (w2 - wbar)) * inv_t;
+            const float c0_own = 0.5f * ((1.f - sm0) + gd0 * L1.dd_dw), c1_own = 0.5f * ((1.f - sm1) + gd1 * L2.dd_dw),
+                        c2_own = 0.5f * ((1.f - sm2) + gd2 * L3.dd_dw);
+            if (live && owner && s_live)
+                acc_gs += (double)(gd0 * L1.dd_ds) + (double)(gd1 * L2.dd_ds) + (double)(gd2 * L3.dd_ds);
+            // ---- phase C: row gradients from the rows still in registers
+            const int cp_own = live ? cpos_own : -2;                        // -2: dropped triplet, -1: positive not tabled
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int cpos = BQ(cp_own, q);
+                const bool lv = cpos > -2;
+                const float c0 = BQ(c0_own, q), c1 = BQ(c1_own, q), c2 = BQ(c2_own, q);
+                const int ia = BQ(ia_own, q), ip = BQ(ip_own, q), in = BQ(in_own, q);
+                if (lv) {
+                    if (ia != ia_have) {                                    // (only when the anchor changed inside the batch)
+                        IO::load(xn, E, ia, s, av);
+                        ia_have = ia;
+                    }
+                    if (ia != cur) {
+                        if (cur >= 0) {
+#pragma unroll
+                            for (int j = 0; j < EPL; ++j) atomicAdd(gxn + (unsigned)(cur * E + s * EPL + j), acc_a[j]);
+                        }
+                        cur = ia;
+#pragma unroll
+                        for (int j = 0; j < EPL; ++j) acc_a[j] = 0.f;
+                    }
+#pragma unroll
+                    for (int j = 0; j < EPL; ++j) acc_a[j] += c0 * P[q][j] + c1 * Ng[q][j];
+                    if (cpos >= 0) {
+#pragma unroll
+                        for (int j = 0; j < EPL; ++j) atomicAdd(cache + cpos * TS + j * SUB + s, c0 * av[j] + c2 * Ng[q][j]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < EPL; ++j) atomicAdd(gxn + (unsigned)(ip * E + s * EPL + j), c0 * av[j] + c2 * Ng[q][j]);
+                    }
+                }
+                {
+                    const unsigned long long lbal = __ballot(lv);                 // all 8 lanes of a kept group are set
+                    const int n_live = __popcll(lbal) >> 3;
+                    if (lv) {
+                        const int rank_q = __popcll(lbal & ((1ull << (lane & ~7)) - 1ull)) >> 3;
+                        const int slot = (qh + qn + rank_q) & 15;
+                        float* qr = qrows + slot * LD + s * EPL;
+#pragma unroll
+                        for (int j = 0; j < EPL; ++j) qr[j] = c1 * av[j] + c2 * P[q][j];
+                        if (s == 0) qid[slot] = in;
+                    }
+                    qn += n_live;
+                    if (qn >= 8) {
+                        constexpr int RPI = 64 / E;
+#pragma unroll
+                        for (int r = 0; r < EPL; ++r) {
+                            const int slot = (qh + r * RPI + lane / E) & 15, e = lane % E;
+                            atomicAdd(gxn + (unsigned)(qid[slot] * E + e), qrows[slot * LD + e]);
+                        }
+                        qh = (qh + 8) & 15;
+                        qn -= 8;
+                    }
+                }
+            }
+        }
+    }
+    if (GRAD && qn > 0) {                                               // the ring's last (fewer than eight) rows
+        constexpr int RPI = 64 / E;
+#pragma unroll
+        for (int r = 0; r < EPL; ++r) {
+            const int t_ = r * RPI + lane / E, e = lane % E;
+            const int slot = (qh + t_) & 15;
+            if (t_ < qn) atomicAdd(gxn + (unsigned)(qid[slot] * E + e), qrows[slot * LD + e]);
+        }
+    }
+    if (GRAD && cur >= 0) {
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) atomicAdd(gxn + (unsigned)(cur * E + s * EPL + j), acc_a[j]);
+    }
+    const double lt = hpcs_block_sum<double>(acc_loss, red);
+    if (threadIdx.x == 0 && lt != 0.0) atomicAdd(loss_sum, lt);
+    const double kt = hpcs_block_sum<double>((double)kept, red);
+    if (threadIdx.x == 0 && kt != 0.0) atomicAdd(kept_out, (unsigned long long)kt);
+    if (GRAD) {
+        const double gt = hpcs_block_sum<double>(acc_gs, red);
+        if (threadIdx.x == 0 && gt != 0.0) atomicAdd(gscale, gt);
+        __syncthreads();
+        // flush the positive table: row r of the class -> point order[off_cb + r]; 64/E rows per wave instruction
+        const int rows = min(RC, cb_sh[2]);
+        const int off_cb = cb_sh[1];
+        constexpr int RPW = 64 / E;
+        const int wave = threadIdx.x >> 6;
+        for (int r0 = wave * RPW; r0 < rows; r0 += (SB_THREADS / 64) * RPW) {
+            const int r = r0 + lane / E, e = lane % E;
+            if (r < rows) {
+                const float v = cache[r * TS + (e % EPL) * SUB + e / EPL];
+                if (v != 0.f) atomicAdd(gxn + (int64_t)order[off_cb + r] * E + e, v);
+            }
+        }
+    }
+}
+#undef BQ
+
 template <bool BWD>
 int launch_hyphc(const float* xn, int E, const int64_t* a, const int64_t* p, const int64_t* n, const int64_t* count,
                  int64_t T_cap, const float* scale, float temperature, float margin, int kind, const int64_t* norm_count,
@@ -1624,6 +1876,11 @@ extern "C" int hpcs_hyphc_sampled(const float* xn, const int64_t* labels, const 
     // amortises the positive table's zero/flush best.  The triplet stream depends on (seed, t) only, not on this.
     static int n_cu = 0;
     static int seg_env = -1;
+    // kernel variant: 4 (default, r03: four triplets per group and batch, rows kept in registers) | 8 (r02: eight, rows
+    // gathered twice); HPCS_SAMPLED_V, read on every call (A/B tests)
+    const char* ve = getenv("HPCS_SAMPLED_V");
+    // (E = 64 stays on the r02 kernel: eight rows of 8 registers spill at the 128-register cap)
+    const int variant = ((ve && ve[0] == '8') || T >= (int64_t)0x7F000000 || E == 64) ? 8 : 4;
     if (n_cu == 0) {
         int dev = 0, v = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
@@ -1656,24 +1913,27 @@ extern "C" int hpcs_hyphc_sampled(const float* xn, const int64_t* labels, const 
     int RC = grad ? (int)((128 * 1024 - slab_bytes) / ((E + 8) * sizeof(float))) : 0;     // rows of the positive table
     if (RC > 1024) RC = 1024;
     const size_t lds = (size_t)RC * (E + 8) * sizeof(float) + slab_bytes;
-#define HPCS_SAMPLED_CASE(EPL)                                                                                        \
-    if (E == 8 * EPL) {                                                                                               \
+#define HPCS_SAMPLED_LAUNCH(KERNEL, EPL)                                                                              \
         if (grad) {                                                                                                   \
-            (void)hipFuncSetAttribute((const void*)hyphc_sampled_kernel<EPL, true>,                                   \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                          \
-            hipLaunchKernelGGL((hyphc_sampled_kernel<EPL, true>), grid, dim3(SB_THREADS), lds, ST, xn, labels, order, \
+            (void)hipFuncSetAttribute((const void*)KERNEL<EPL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((KERNEL<EPL, true>), grid, dim3(SB_THREADS), lds, ST, xn, labels, order,               \
                                offsets, cls_toff, cls_k, C, M, T, seed, seed_dev, scale, temperature, margin, kind, RC, loss_sum, \
                                (unsigned long long*)kept, gxn, gscale, a_dbg, p_dbg, n_dbg, perm_mul, seg_len);                \
         } else {                                                                                                      \
-            hipLaunchKernelGGL((hyphc_sampled_kernel<EPL, false>), grid, dim3(SB_THREADS), lds, ST, xn, labels, order, \
+            hipLaunchKernelGGL((KERNEL<EPL, false>), grid, dim3(SB_THREADS), lds, ST, xn, labels, order,              \
                                offsets, cls_toff, cls_k, C, M, T, seed, seed_dev, scale, temperature, margin, kind, RC, loss_sum, \
                                (unsigned long long*)kept, gxn, gscale, a_dbg, p_dbg, n_dbg, perm_mul, seg_len);                \
-        }                                                                                                             \
+        }
+#define HPCS_SAMPLED_CASE(EPL)                                                                                        \
+    if (E == 8 * EPL) {                                                                                               \
+        if (variant == 8) { HPCS_SAMPLED_LAUNCH(hyphc_sampled_kernel, EPL) }                                          \
+        else { HPCS_SAMPLED_LAUNCH(hyphc_sampled4_kernel, EPL) }                                                      \
     }
     HPCS_SAMPLED_CASE(2)
     HPCS_SAMPLED_CASE(4)
     HPCS_SAMPLED_CASE(8)
 #undef HPCS_SAMPLED_CASE
+#undef HPCS_SAMPLED_LAUNCH
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;
 }

@@ -197,18 +197,33 @@ def gemm_WtG(W, G, nb, M, Nc, out=None, accumulate=False):
     return out
 
 
+NT_FUSED = __import__("os").environ.get("HPCS_NT_FUSED", "1") != "0"     # A/B: 0 = split partials summed by follow-up launches
+
+
+def _nt_call(G, ldg, sGo, X, ldx, sXo, M, K, Nc, nb, dst_ptr, lddw, accumulate, device):
+    """hpcs_gemm_nt with its split reduction inside the launch (tickets from the step's zeroed arena), or -- HPCS_NT_FUSED=0 --
+    followed by the split_reduce launches."""
+    nbytes = call("hpcs_gemm_nt_workspace", M, K, Nc, nb, 1)
+    ws = torch.empty(nbytes // 4 + 4, device=device, dtype=torch.float32)
+    if NT_FUSED:
+        nt = call("hpcs_gemm_nt_tickets", M, K, Nc, nb, 1)
+        tickets = _zeros64((nt + 1) // 2, device)             # 32-bit words, zero; the kernel leaves them zero
+        call("hpcs_gemm_nt_fused", G, ldg, sGo, 0, X, ldx, sXo, 0, M, K, Nc, nb, 1, dst_ptr, lddw, accumulate, ws, nbytes,
+             tickets, nt)
+    else:
+        call("hpcs_gemm_nt", G, ldg, sGo, 0, X, ldx, sXo, 0, M, K, Nc, nb, 1, dst_ptr, lddw, accumulate, ws, nbytes)
+
+
 def gemm_GXt(G, X, nb, M, K, Nc, out=None):
     """dW (M x K) = sum_b G[b] (M x Nc) @ X[b]^T (K x Nc).  out: a [M, K] view with unit column stride that the result is
     ADDED into (a slice of the flat gradient bucket: no temporary, no separate add)."""
-    nbytes = call("hpcs_gemm_nt_workspace", M, K, Nc, nb, 1)
-    ws = torch.empty(nbytes // 4 + 4, device=G.device, dtype=torch.float32)
     if out is not None:
         if tuple(out.shape) != (M, K) or out.stride(1) != 1:
             raise ValueError("gemm_GXt: out must be an [M, K] view with contiguous rows")
-        call("hpcs_gemm_nt", G, Nc, M * Nc, 0, X, Nc, K * Nc, 0, M, K, Nc, nb, 1, out.data_ptr(), out.stride(0), 1, ws, nbytes)
+        _nt_call(G, Nc, M * Nc, X, Nc, K * Nc, M, K, Nc, nb, out.data_ptr(), out.stride(0), 1, G.device)
         return out
     dW = torch.empty(M, K, device=G.device, dtype=torch.float32)
-    call("hpcs_gemm_nt", G, Nc, M * Nc, 0, X, Nc, K * Nc, 0, M, K, Nc, nb, 1, dW, K, 0, ws, nbytes)
+    _nt_call(G, Nc, M * Nc, X, Nc, K * Nc, M, K, Nc, nb, dW.data_ptr(), K, 0, G.device)
     return dW
 
 
@@ -423,10 +438,7 @@ def chan_mix(x, W, rowbias=None, sink=None):
 # ------------------------------------------------------------------------------------------------ row-vector linear
 def _nt_into(G, ldg, X, ldx, R, M, K, out, ldo, accumulate=False):
     """out[R, M] (row stride ldo) = G[R, K] @ X[M, K]^T, reduction over the contiguous index (split over workgroups)."""
-    nbytes = call("hpcs_gemm_nt_workspace", R, M, K, 1, 1)
-    ws = torch.empty(nbytes // 4 + 4, device=G.device, dtype=torch.float32)
-    call("hpcs_gemm_nt", G.data_ptr(), ldg, 0, 0, X.data_ptr(), ldx, 0, 0, R, M, K, 1, 1, out.data_ptr(), ldo,
-         1 if accumulate else 0, ws, nbytes)
+    _nt_call(G.data_ptr(), ldg, 0, X.data_ptr(), ldx, 0, R, M, K, 1, out.data_ptr(), ldo, 1 if accumulate else 0, G.device)
     return out
 
 

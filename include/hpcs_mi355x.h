@@ -88,6 +88,15 @@ typedef struct {
 } hpcs_prep_desc;
 int hpcs_prep_weights_multi(const hpcs_prep_desc* desc_dev, int n, hpcs_stream_t stream);
 size_t hpcs_gemm_nt_workspace(int M, int Kx, int Nc, int n_outer, int n_inner);
+/* hpcs_gemm_nt_fused: the same product with the split reduction INSIDE the launch (last-arriving workgroup per slice of
+ * splits, then per tile; fixed summation order; no follow-up reduce launches).  `tickets`: hpcs_gemm_nt_tickets() int32
+ * words, ZERO before the first use (every call leaves them zero again; the step takes them from its once-per-step zeroed
+ * arena).  Same `ws`. */
+size_t hpcs_gemm_nt_tickets(int M, int Kx, int Nc, int n_outer, int n_inner);
+int hpcs_gemm_nt_fused(const float* G, int ldg, int64_t strideG_o, int64_t strideG_i, const float* X, int ldx,
+                       int64_t strideX_o, int64_t strideX_i, int M, int Kx, int Nc, int n_outer, int n_inner, float* dW,
+                       int lddw, int accumulate, void* ws, size_t ws_bytes, int32_t* tickets, size_t n_tickets,
+                       hpcs_stream_t stream);
 int hpcs_gemm_nt(const float* G, int ldg, int64_t strideG_o, int64_t strideG_i, const float* X, int ldx,
                  int64_t strideX_o, int64_t strideX_i, int M, int Kx, int Nc, int n_outer, int n_inner, float* dW,
                  int lddw, int accumulate, void* ws, size_t ws_bytes, hpcs_stream_t stream);

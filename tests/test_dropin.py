@@ -169,10 +169,24 @@ def test_caller_shaped_training_through_the_public_api_matches_the_oracle():
                 # triplets -- the end-to-end losses are held to the trajectory bands below, the operators to 1e-5 here.)
                 torch.manual_seed(500)
                 xp0 = emb[0].reshape(-1, E)
-                lh0, lm0, _ = OM.metric_hyperbolic_loss(xp0, tgt.reshape(-1), torch.tensor([1e-3]), W0, margin=0.35,
-                                                        t_per_anchor=TPA, fraction=1.2, temperature=0.05, cosface=True)
+                lh0, lm0, trip0 = OM.metric_hyperbolic_loss(xp0, tgt.reshape(-1), torch.tensor([1e-3]), W0, margin=0.35,
+                                                            t_per_anchor=TPA, fraction=1.2, temperature=0.05, cosface=True)
                 assert abs(float(out["loss_metric"]) - float(lm0)) <= 1e-5 * abs(float(lm0)), (float(out["loss_metric"]), float(lm0))
-                assert abs(float(out["loss_hyp"]) - 0.1 * float(lh0)) <= 1e-5 * abs(0.1 * float(lh0)), (float(out["loss_hyp"]), float(lh0))
+                # HypHC on the triplets the HIP miner KEPT (the `easy` filter decides on sim(a,p) - sim(a,n) > 0, and an
+                # untrained extractor maps all points to nearly parallel embeddings: thousands of triplets sit within fp32
+                # rounding of 0, so two fp32 evaluations of the filter keep different sets -- the reference's own included)
+                a_, p_, n_, c_ = model.metric_hyp_loss.last_triplets
+                c_ = int(c_)
+                kept = (a_[:c_].cpu(), p_[:c_].cpu(), n_[:c_].cpu())
+                lh_same = OM.hyphc_loss(xp0.double(), kept, torch.tensor([1e-3], dtype=torch.float64), 0.05)
+                assert abs(float(out["loss_hyp"]) - 0.1 * float(lh_same)) <= 1e-5 * abs(0.1 * float(lh_same)), \
+                    (float(out["loss_hyp"]), 0.1 * float(lh_same))
+                # ... and the two kept sets differ only at such near-ties of the filter quantity (fp64 on these embeddings)
+                xn64 = torch.nn.functional.normalize(xp0.double(), dim=1)
+                key = lambda t: set(zip(t[0].tolist(), t[1].tolist(), t[2].tolist()))        # noqa: E731
+                for (ia, ip, in_) in key(kept) ^ key(trip0):
+                    tm = 0.5 * float((xn64[ia] * xn64[ip]).sum() - (xn64[ia] * xn64[in_]).sum())
+                    assert abs(tm) <= 2e-6, (ia, ip, in_, tm)
             total = out["loss_hyp"] + out["loss_metric"]
             total.backward()
             opt.step()

@@ -180,6 +180,39 @@ def test_gemm_nt(M, Kx, Nc, nb):
     torch.testing.assert_close(dW.cpu().double(), want, rtol=1e-5, atol=2e-6 * float(want.abs().max()) * np.sqrt(Nc * nb))
 
 
+@pytest.mark.parametrize("M,Kx,Nc,nb", [(42, 42, 5000, 3), (42, 21, 61440, 8), (341, 63, 3 * 256, 2), (682, 682, 3 * 64, 2),
+                                        (256, 1, 1, 6), (3, 170, 96, 4), (64, 256, 1024, 32)])
+def test_gemm_nt_fused_reduction_equals_the_two_launch_form(M, Kx, Nc, nb):
+    """hpcs_gemm_nt_fused: the split partials are summed by the last-arriving workgroup inside the launch (per slice of
+    splits, then per tile; write-through partials, agent-scope tickets).  Checked against fp64, against the separate
+    split_reduce launches (same partials, another fixed order: equal to fp32 rounding of the sum), bit-reproducible run to
+    run, with the SAME ticket words reused by a second call (the kernel leaves them zero) and accumulate on / off.
+    (42, 21, 61440, 8) is the EdgeConv weight-gradient shape: one tile, hundreds of splits, two reduction levels."""
+    G = det_normalish((nb, M, Nc), 600 + M).to(dev)
+    X = det_normalish((nb, Kx, Nc), 700 + Kx).to(dev)
+    nbytes = _lib.call("hpcs_gemm_nt_workspace", M, Kx, Nc, nb, 1)
+    nt = _lib.call("hpcs_gemm_nt_tickets", M, Kx, Nc, nb, 1)
+    assert nt >= 1
+    ws = torch.empty(nbytes // 4 + 1, device=dev)
+    tickets = torch.zeros(nt, dtype=torch.int32, device=dev)
+    want = torch.einsum("bmc,bkc->mk", G.double().cpu(), X.double().cpu())
+    tol = dict(rtol=1e-5, atol=2e-6 * float(want.abs().max()) * np.sqrt(Nc * nb))
+    outs = []
+    for acc in (0, 1, 1):
+        dW = torch.full((M, Kx), 3.0, device=dev)
+        _lib.call("hpcs_gemm_nt_fused", G, Nc, M * Nc, 0, X, Nc, Kx * Nc, 0, M, Kx, Nc, nb, 1, dW, Kx, acc, ws, nbytes, tickets, nt)
+        torch.cuda.synchronize()
+        assert int(tickets.abs().sum()) == 0                               # left zero for the next call
+        torch.testing.assert_close(dW.cpu().double(), want + (3.0 if acc else 0.0), **tol)
+        outs.append(dW.clone())
+    assert torch.equal(outs[1], outs[2])                                   # fixed summation order
+    ref = torch.full((M, Kx), 3.0, device=dev)
+    _lib.call("hpcs_gemm_nt", G, Nc, M * Nc, 0, X, Nc, Kx * Nc, 0, M, Kx, Nc, nb, 1, ref, Kx, 1, ws, nbytes)
+    torch.testing.assert_close(outs[1], ref, rtol=2e-6, atol=1e-6 * float(want.abs().max()))
+    with pytest.raises(_lib.HpcsNativeError):
+        _lib.call("hpcs_gemm_nt_fused", G, Nc, M * Nc, 0, X, Nc, Kx * Nc, 0, M, Kx, Nc, nb, 1, ref, Kx, 1, ws, nbytes, tickets, 0)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("R,K,M,ld", [(32, 2110, 256, 2299), (96, 341, 682, 682), (5, 7, 3, 9)])
 def test_row_linear_matches_fp64(R, K, M, ld):
