@@ -340,23 +340,36 @@ __global__ __launch_bounds__(256) void gemm_tn_small_kernel(
 // fp64 arena: one fill per step); the last reducer leaves them zero again.
 struct NtFuse {
     unsigned* tickets;        // [tiles * (slices + 1)]: per (tile, slice) arrivals, then per tile slice arrivals; nullptr: off
-    float* stage;             // [slices][M * Kx] slice sums (two-level only)
+    float* stage;             // [slices][tiles][TE] slice sums (two-level only)
     float* dW;
     int lddw, accumulate, slice_len, slices;
+    unsigned part_bytes, stage_bytes;     // extents of the two write-through buffers (buffer descriptors)
 };
-__device__ __forceinline__ void nt_store_wt(float* p, float v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+typedef unsigned int nt_v4u __attribute__((ext_vector_type(4)));
+// 16-byte write-through store / L1-bypassing load (aux 16 = sc1) through a raw buffer descriptor built from wave-uniform values
+__device__ __forceinline__ void nt_store16_wt(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, float4 v) {
+    nt_v4u u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(u, rs, byte_off, 0, 16);
 }
-__device__ __forceinline__ float nt_load_wt(const float* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ float4 nt_load16_wt(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
+    const nt_v4u u = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 16);
+    return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
 }
-// Called by EVERY thread of the workgroup after its partial stores.  `sh` is one int of LDS.  Tile = rows [m0, m0 + BMt) x
-// columns [x0, x0 + BNt) of the M x Kx result; `split` is this workgroup's split index, `tile` its tile index.
-template <int NT>
-__device__ __forceinline__ void nt_fused_reduce(const NtFuse& f, const float* __restrict__ part, int nsplit, int split, int tile,
-                                                int tiles, int M, int Kx, int m0, int x0, int BMt, int BNt, int* sh) {
+// Called by EVERY thread of the workgroup once its finished TILE sits in LDS (`tl`: TR rows x TC columns, row-major, dense;
+// rows / columns beyond M / Kx hold zeros).  Partials are TILE-MAJOR in the workspace -- part[split][tile][TR*TC] -- so that
+// the publish and the reducer's reads are whole 16-byte accesses: the first version (element-major partials, one dword
+// write-through store and one dword load per element, eight in flight) made the last arriver a 0.1-0.5 ms serial tail
+// (gemm_nt 1.75 -> 3.2 ms per step).  `sh`: one int of LDS outside `tl`.
+template <int NT, int TR, int TC>
+__device__ __forceinline__ void nt_fused_reduce(const NtFuse& f, float* __restrict__ part, const float* tl, int nsplit, int split,
+                                                int tile, int tiles, int M, int Kx, int m0, int x0, int* sh) {
+    constexpr int TE = TR * TC, T4 = TE / 4;
+    static_assert(TE % 4 == 0 && TC % 4 == 0, "whole float4 rows");
     const int tid = threadIdx.x;
-    const int64_t ne = (int64_t)M * Kx;
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(part, 0, (int)f.part_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(f.stage, 0, (int)f.stage_bytes, 0x00020000);
+    const unsigned my_base = (unsigned)((split * tiles + tile) * TE) * 4u;
+    for (int q = tid; q < T4; q += NT) nt_store16_wt(rp, my_base + 16u * q, *reinterpret_cast<const float4*>(tl + 4 * q));
     const int slice = split / f.slice_len;
     const int s0 = slice * f.slice_len, s1 = min(nsplit, s0 + f.slice_len);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's write-through partial stores have been performed
@@ -367,27 +380,33 @@ __device__ __forceinline__ void nt_fused_reduce(const NtFuse& f, const float* __
     __syncthreads();
     if (!*sh) return;
     const bool two = f.slices > 1;
-    // level 1: sum the slice's partials in split order (8 independent loads in flight per element)
-    for (int e = tid; e < BMt * BNt; e += NT) {
-        const int row = m0 + e / BNt, col = x0 + e % BNt;
-        if (row >= M || col >= Kx) continue;
-        const int64_t o = (int64_t)row * Kx + col;
-        float acc = 0.f;
+    auto finish = [&](int q, float4 a) {                      // four consecutive columns of one tile row -> dW
+        const int row = m0 + (4 * q) / TC, col = x0 + (4 * q) % TC;
+        if (row >= M) return;
+        float* d = f.dW + (int64_t)row * f.lddw + col;
+        const float v[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (col + e < Kx) d[e] = f.accumulate ? d[e] + v[e] : v[e];
+    };
+    // level 1: the slice's partials in split order, 8 independent 16-byte loads in flight per float4 of the tile
+    for (int q = tid; q < T4; q += NT) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        const unsigned o = (unsigned)(tile * TE) * 4u + 16u * q, pitch = (unsigned)(tiles * TE) * 4u;
         int sp = s0;
         for (; sp + 8 <= s1; sp += 8) {
-            float v[8];
+            float4 v[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = nt_load_wt(part + (int64_t)(sp + q) * ne + o);
+            for (int u = 0; u < 8; ++u) v[u] = nt_load16_wt(rp, (unsigned)(sp + u) * pitch + o);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) acc += v[q];
+            for (int u = 0; u < 8; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
         }
-        for (; sp < s1; ++sp) acc += nt_load_wt(part + (int64_t)sp * ne + o);
-        if (two) {
-            nt_store_wt(f.stage + (int64_t)slice * ne + o, acc);
-        } else {
-            float* d = f.dW + (int64_t)row * f.lddw + col;
-            *d = f.accumulate ? *d + acc : acc;
+        for (; sp < s1; ++sp) {
+            const float4 v = nt_load16_wt(rp, (unsigned)sp * pitch + o);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
         }
+        if (two) nt_store16_wt(rs, (unsigned)((slice * tiles + tile) * TE) * 4u + 16u * q, a);
+        else finish(q, a);
     }
     if (tid == 0) __hip_atomic_store(f.tickets + (int64_t)tile * f.slices + slice, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (!two) return;
@@ -398,22 +417,22 @@ __device__ __forceinline__ void nt_fused_reduce(const NtFuse& f, const float* __
                                      __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(f.slices - 1);
     __syncthreads();
     if (!*sh) return;
-    for (int e = tid; e < BMt * BNt; e += NT) {
-        const int row = m0 + e / BNt, col = x0 + e % BNt;
-        if (row >= M || col >= Kx) continue;
-        const int64_t o = (int64_t)row * Kx + col;
-        float acc = 0.f;
+    for (int q = tid; q < T4; q += NT) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        const unsigned o = (unsigned)(tile * TE) * 4u + 16u * q, pitch = (unsigned)(tiles * TE) * 4u;
         int sl = 0;
         for (; sl + 8 <= f.slices; sl += 8) {
-            float v[8];
+            float4 v[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = nt_load_wt(f.stage + (int64_t)(sl + q) * ne + o);
+            for (int u = 0; u < 8; ++u) v[u] = nt_load16_wt(rs, (unsigned)(sl + u) * pitch + o);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) acc += v[q];
+            for (int u = 0; u < 8; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
         }
-        for (; sl < f.slices; ++sl) acc += nt_load_wt(f.stage + (int64_t)sl * ne + o);
-        float* d = f.dW + (int64_t)row * f.lddw + col;
-        *d = f.accumulate ? *d + acc : acc;
+        for (; sl < f.slices; ++sl) {
+            const float4 v = nt_load16_wt(rs, (unsigned)sl * pitch + o);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        finish(q, a);
     }
     if (tid == 0) __hip_atomic_store(f.tickets + (int64_t)tiles * f.slices + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -435,8 +454,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(
     constexpr bool V4 = BM == 64;
     constexpr int LD = V4 ? BKC + 4 : BKC + 1;
     constexpr int G_LD = BM * BKC / 4 / NT, X_LD = BN * BKC / 4 / NT;
-    __shared__ __attribute__((aligned(16))) float Gs[BM][LD];
-    __shared__ __attribute__((aligned(16))) float Xs[BN][LD];
+    // one LDS array (operand tiles; reused as the dense output tile + flag by the in-launch reduction)
+    constexpr int SM_FLOATS = (BM + BN) * LD > BM * BN + 4 || BM > 64 ? (BM + BN) * LD : BM * BN + 4;
+    __shared__ __attribute__((aligned(16))) float sm_all[SM_FLOATS];
+    float (*Gs)[LD] = reinterpret_cast<float (*)[LD]>(sm_all);
+    float (*Xs)[LD] = reinterpret_cast<float (*)[LD]>(sm_all + BM * LD);
 
     const int tile = blockIdx.x % (tilesM * tilesK);
     const int split = blockIdx.x / (tilesM * tilesK);
@@ -543,8 +565,28 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(
                 }
         }
     }
+    if constexpr (BM <= 64) {
+        if (fuse.tickets != nullptr) {
+            // dense BM x BN tile through LDS (the operand tiles are dead), then 16-byte write-through publishes + tickets
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int cl = wn * (BN / WN) + j * 32 + lr;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rl = wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                        sm_all[rl * BN + cl] = acc[i][j][r];
+                    }
+                }
+            __syncthreads();
+            nt_fused_reduce<NT, BM, BN>(fuse, part, sm_all, nsplit, split, tile, tilesM * tilesK, M, Kx, m0, x0,
+                                        reinterpret_cast<int*>(sm_all + BM * BN));
+            return;
+        }
+    }
     float* P = part + (int64_t)split * M * Kx;
-    const bool fused = fuse.tickets != nullptr;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -553,16 +595,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                if (row < M && col < Kx) {
-                    if (fused) nt_store_wt(P + (int64_t)row * Kx + col, acc[i][j][r]);
-                    else P[(int64_t)row * Kx + col] = acc[i][j][r];
-                }
+                if (row < M && col < Kx) P[(int64_t)row * Kx + col] = acc[i][j][r];
             }
         }
-    if (fused) {
-        __syncthreads();                                   // the operand tiles are dead: their first word serves as the flag
-        nt_fused_reduce<NT>(fuse, part, nsplit, split, tile, tilesM * tilesK, M, Kx, m0, x0, BM, BN, reinterpret_cast<int*>(&Gs[0][0]));
-    }
 }
 
 // EdgeConv weight gradients: one output tile with M, Kx <= 48 over millions of columns.  On the 64x64 tile of the
@@ -677,9 +712,8 @@ __global__ __launch_bounds__(256) void gemm_nt_edge_kernel(
         for (int e = tid; e < M * Kx; e += NT) P[e] = tile[(e / Kx) * NE_T + e % Kx];
         return;
     }
-    for (int e = tid; e < M * Kx; e += NT) nt_store_wt(P + e, tile[(e / Kx) * NE_T + e % Kx]);
-    __syncthreads();                                       // the staged tile has been read: its first word serves as the flag
-    nt_fused_reduce<NT>(fuse, part, nsplit, split, 0, 1, M, Kx, 0, 0, NE_T, NE_T, reinterpret_cast<int*>(tile));
+    // (the 48 x 48 tile is dense in LDS after the wave reduction; its padding rows / columns are zeros)
+    nt_fused_reduce<NT, NE_T, NE_T>(fuse, part, tile, nsplit, split, 0, 1, M, Kx, 0, 0, reinterpret_cast<int*>(tile + NE_T * NE_T));
 }
 
 // Sums the split partials in a FIXED order (deterministic).  64 outputs per workgroup, 16 waves each own every
@@ -887,7 +921,11 @@ extern "C" size_t hpcs_gemm_nt_workspace(int M, int Kx, int Nc, int n_outer, int
     if (M <= 0 || Kx <= 0 || Nc <= 0 || n_outer <= 0 || n_inner <= 0) return 0;
     const NtPlan p = nt_plan(M, Kx, Nc, n_outer * n_inner);
     const size_t stage = sr_two_level(p.nsplit, (int64_t)M * Kx) ? (size_t)SR_SLICES * M * Kx : 0;
-    return ((size_t)p.nsplit * M * Kx + stage) * sizeof(float);
+    const size_t plain = ((size_t)p.nsplit * M * Kx + stage) * sizeof(float);
+    // the in-launch reduction keeps its partials tile-major and dense (whole tiles, padding included)
+    const size_t te = (p.tilesM * p.tilesK == 1 && M <= NE_T && Kx <= NE_T) ? (size_t)NE_T * NE_T : (size_t)p.tile * p.tile;
+    const size_t fused = ((size_t)p.nsplit + SR_SLICES) * p.tilesM * p.tilesK * te * sizeof(float);
+    return plain > fused ? plain : fused;
 }
 
 // number of 32-bit tickets hpcs_gemm_nt_fused needs (zeroed by the caller before the FIRST use; left zero by every call)
@@ -910,8 +948,7 @@ static int gemm_nt_impl(const float* G, int ldg, int64_t strideG_o, int64_t stri
     const int nb = n_outer * n_inner;
     const NtPlan p = nt_plan(M, Kx, Nc, nb);
     const bool two_level = sr_two_level(p.nsplit, (int64_t)M * Kx);
-    if (ws_bytes < ((size_t)p.nsplit * M * Kx + (two_level ? (size_t)SR_SLICES * M * Kx : 0)) * sizeof(float))
-        return HPCS_ERR_WORKSPACE;
+    if (ws_bytes < hpcs_gemm_nt_workspace(M, Kx, Nc, n_outer, n_inner)) return HPCS_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int vecG = (ldg % 4 == 0) && (strideG_o % 4 == 0) && (strideG_i % 4 == 0) && aligned16(G);
     const int vecX = (ldx % 4 == 0) && (strideX_o % 4 == 0) && (strideX_i % 4 == 0) && aligned16(X);
@@ -920,10 +957,18 @@ static int gemm_nt_impl(const float* G, int ldg, int64_t strideG_o, int64_t stri
     const int slice_len = two_level ? hpcs_cdiv(p.nsplit, SR_SLICES) : p.nsplit;
     const int slices = hpcs_cdiv(p.nsplit, slice_len);
     float* stage = (float*)ws + (size_t)p.nsplit * ne;
-    NtFuse fuse{nullptr, stage, dW, lddw, accumulate, slice_len, slices};
-    if (tickets) {
-        if (n_tickets < (size_t)p.tilesM * p.tilesK * (slices + 1)) return HPCS_ERR_WORKSPACE;
+    const bool edge = p.tilesM * p.tilesK == 1 && M <= NE_T && Kx <= NE_T;
+    NtFuse fuse{nullptr, stage, dW, lddw, accumulate, slice_len, slices, 0u, 0u};
+    if (tickets && n_tickets < (size_t)p.tilesM * p.tilesK * (slices + 1)) return HPCS_ERR_WORKSPACE;
+    if (tickets && p.tile != 128) {           // (the 128 x 128 tile of the 682 x 682 layer does not fit the staging LDS: two launches)
+        const size_t te = edge ? (size_t)NE_T * NE_T : (size_t)p.tile * p.tile;
+        const size_t pb = (size_t)p.nsplit * p.tilesM * p.tilesK * te * sizeof(float);
+        const size_t sb = (size_t)slices * p.tilesM * p.tilesK * te * sizeof(float);
+        if (pb >= (1ull << 31) || sb >= (1ull << 31)) return HPCS_ERR_UNSUPPORTED;
         fuse.tickets = tickets;
+        fuse.stage = (float*)((char*)ws + pb);
+        fuse.part_bytes = (unsigned)pb;
+        fuse.stage_bytes = (unsigned)(sb ? sb : 16);
     }
     if (p.tilesM * p.tilesK == 1 && M <= NE_T && Kx <= NE_T)
         hipLaunchKernelGGL(gemm_nt_edge_kernel, dim3((unsigned)blocks), dim3(256), 0, st, G, ldg, strideG_o, strideG_i, X, ldx,
