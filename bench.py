@@ -379,7 +379,34 @@ def main():
             step._eager_step(pts_d, cat_d, tgt_d, tgt)
         torch.cuda.synchronize()
         prof_extra, _lib.PROFILE = _lib.PROFILE, None
+    # multi-rank diagnostics: per-rank step time, host enqueue cost and the all-reduce's event span
+    dp_diag = None
     if world > 1:
+        ar = []
+        real_ar = step.bucket.all_reduce_mean
+
+        def timed_ar(*a_, **k_):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            real_ar(*a_, **k_)
+            e1.record()
+            ar.append((e0, e1))
+        step.bucket.all_reduce_mean = timed_ar
+        for _ in range(EXTRA_STEPS):
+            step._eager_step(pts_d, cat_d, tgt_d, tgt)
+        torch.cuda.synchronize()
+        step.bucket.all_reduce_mean = real_ar
+        mine = torch.tensor([dt / args.steps * 1e3, host_ms, sum(a_.elapsed_time(b_) for a_, b_ in ar) / max(len(ar), 1)],
+                            device=device)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        cols = torch.stack(allr).cpu()
+        dp_diag = {"per_rank_ms_per_step": [round(float(v), 3) for v in cols[:, 0]],
+                   "per_rank_host_enqueue_ms": [round(float(v), 3) for v in cols[:, 1]],
+                   "per_rank_allreduce_span_ms": [round(float(v), 3) for v in cols[:, 2]],
+                   "allreduce_bytes": int(step.bucket.numel * 4),
+                   "note": "all-reduce span = HIP events around dist.all_reduce + the 1/world scale on the step's stream (it "
+                           "includes waiting for the slowest rank); measured in extra eager steps after the timed region"}
         dist.barrier()
     kept_window = [int(k_.item()) for k_ in kept_hist]
 
@@ -421,6 +448,7 @@ def main():
                                       "no host sync; last step: acc=%.4f iou=%.4f" % (float(losses["acc"]), float(losses["iou"])),
                    "final_total_loss": round(loss_val, 6),
                    "host_enqueue_ms_per_step": round(host_ms, 3),
+                   "data_parallel": dp_diag,
                    "triplets_sampled_per_step_rank0": T_s,
                    "triplets_kept_first_and_last_timed_step": kept_window},
     }

@@ -1101,13 +1101,6 @@ __global__ __launch_bounds__(SB_THREADS) void hyphc_sampled4_kernel(
                     }
 #pragma unroll
                     for (int j = 0; j < EPL; ++j) acc_a[j] += c0 * P[q][j] + c1 * Ng[q][j];
-                    if (cpos >= 0) {
-#pragma unroll
-                        for (int j = 0; j < EPL; ++j) atomicAdd(cache + cpos * TS + j * SUB + s, c0 * av[j] + c2 * Ng[q][j]);
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < EPL; ++j) atomicAdd(gxn + (unsigned)(ip * E + s * EPL + j), c0 * av[j] + c2 * Ng[q][j]);
-                    }
                 }
                 {
                     const unsigned long long lbal = __ballot(lv);                 // all 8 lanes of a kept group are set
@@ -1130,6 +1123,17 @@ __global__ __launch_bounds__(SB_THREADS) void hyphc_sampled4_kernel(
                         }
                         qh = (qh + 8) & 15;
                         qn -= 8;
+                    }
+                }
+                // positive row LAST: LDS executes in order, so the ring's reads above would otherwise wait behind these
+                // (slow) ds_add_f32 -- 87 % of the kernel's wait cycles are LDS waits (PMC, r03)
+                if (lv) {
+                    if (cpos >= 0) {
+#pragma unroll
+                        for (int j = 0; j < EPL; ++j) atomicAdd(cache + cpos * TS + j * SUB + s, c0 * av[j] + c2 * Ng[q][j]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < EPL; ++j) atomicAdd(gxn + (unsigned)(ip * E + s * EPL + j), c0 * av[j] + c2 * Ng[q][j]);
                     }
                 }
             }

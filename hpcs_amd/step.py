@@ -276,7 +276,10 @@ class HypHCStep(torch.nn.Module):
             # threads has not run on hardware here (the world-2 test drives the two-graph path with gloo, HPCS_GRAPH=1),
             # and the multi-GPU step is GPU-bound, where eager measured faster anyway
             import torch.distributed as dist
-            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and \
+                    __import__("os").environ.get("HPCS_GRAPH_MULTI", "0") != "1":
+                # HPCS_GRAPH_MULTI=1: measure replay against eager under a multi-rank group too (two graphs around the eager
+                # all-reduce; every step still issues exactly one collective, so ranks may even decide differently)
                 self.use_graph = False
         return (self.use_graph and targets_host is not None and rot is None and drop_masks is None and loss.miner
                 and loss.fused_filter and loss.hyp_miner.rng == "device" and loss.debug_triplets is None

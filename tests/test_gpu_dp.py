@@ -94,6 +94,27 @@ res["graph_captured"] = g._graph is not None and "opt" in g._graph
 res["graph_replicas_equal"] = all(torch.equal(plist[0], q) for q in plist)
 res["graph_losses_finite"] = all(x == x and abs(x) < 1e6 for x in hist)
 res["graph_losses"] = hist
+# ---- (3) a BASELINE configs[4]-shaped shard (N = 2048, k = 40: the slab form of the graph-layer backward) under world 2 --
+B5, N5, k5, C5 = 2, 2048, 40, 6
+torch.manual_seed(3)
+feat5 = VN_DGCNN_partseg(3, E, k=k5, dropout=0.0, pooling="mean", num_categories=16)
+feat5.load_state_dict(det_params(param_shapes(E, 16), 78))
+s5 = HypHCStep(feat5, ExpMap(), hyp_size=E, num_class=C5, lr=1e-3, margin=0.35, t_per_anchor=5, fraction=1.2,
+               train_rotation=None, rng="host").to(dev).train().configure()
+s5.use_graph = False
+broadcast_parameters(s5)
+p5, c5, t5 = bench.synthetic_batch(B5, N5, C5, 16, seed=10 + rank)
+torch.manual_seed(200 + rank)
+o5 = s5.training_step(p5.to(dev), c5.to(dev), t5.to(dev), targets_host=t5)
+torch.cuda.synchronize()
+g5 = torch.cat([p.detach().flatten() for p in s5.parameters()]).cpu()
+plist = [torch.zeros_like(g5) for _ in range(world)]
+dist.all_gather(plist, g5)
+res["cfg5_replicas_equal"] = all(torch.equal(plist[0], q) for q in plist)
+res["cfg5_loss_finite"] = bool(torch.isfinite(o5["total_loss"]))
+res["cfg5_params_finite"] = bool(torch.isfinite(g5).all())
+gn = s5.bucket.flat.detach().cpu()
+res["cfg5_grad_norm"] = float(gn.norm())
 json.dump(res, open(os.path.join(OUT, f"dp_rank{rank}.json"), "w"))
 dist.barrier()
 dist.destroy_process_group()
@@ -126,6 +147,8 @@ def test_hyphc_step_world2_matches_serial_mean_gradient(tmp_path):
     assert r0["bn_running_mean_is_per_replica"]
     for r_ in (r0, r1):
         assert r_["graph_captured"] and r_["graph_replicas_equal"] and r_["graph_losses_finite"], r_
+        # the N = 2048, k = 40 shard (slab backward): replicas identical after the all-reduced step, everything finite
+        assert r_["cfg5_replicas_equal"] and r_["cfg5_loss_finite"] and r_["cfg5_params_finite"] and r_["cfg5_grad_norm"] > 0, r_
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    json.dump({"rank0": r0, "rank1": r1}, open(os.path.join(out, "dp_world2_r02.json"), "w"), indent=1)
+    json.dump({"rank0": r0, "rank1": r1}, open(os.path.join(out, "dp_world2_r03.json"), "w"), indent=1)
