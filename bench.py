@@ -128,7 +128,7 @@ def pmc_traffic(kernel_substr):
 
 EXTRA_STEPS = 3
 HOST_BURST = 3               # steps enqueued back to back from an idle queue to time the host side of a step
-EVENT_EVERY = 4              # dominant-kernel event pairs in every 4th timed step
+EVENT_STEPS = 2              # dominant-kernel event pairs in this many of the timed steps (evenly spaced)
 EXTRA_NOTE = f"HIP events in {EXTRA_STEPS} further steps after the timed region"
 
 
@@ -340,18 +340,24 @@ def main():
     timed = not args.no_kernel_timing
     # HIP events (on the launch stream) around every launch of the two heaviest kernels, live in the timed region:
     # hpcs_gemm_tn calls that dispatch gemm_tn_kernel<128,128,16,2,2> (M > 64 and >= 32 tiles, see gemm.hip) and
-    # hpcs_hyphc_sampled.  An event pair is a barrier packet on each side (on every launch of every step they cost 3 % of
-    # the step), so the pairs are recorded in every EVENT_EVERY-th timed step -- still inside the timed region, still
-    # every launch of those kernels in those steps.  When the steady state replays a hipGraph those sampled steps run
-    # eagerly (events cannot be wrapped around the nodes of a replayed graph).
+    # hpcs_hyphc_sampled.  An event pair is a barrier packet on each side; r03 measured what that does to an EAGER two-stream
+    # step: with pairs in every 4th step the same box gave 10.9 ... 16.2 ms per step run to run (10.6-11.0 without any), so
+    # the pairs are recorded in EVENT_STEPS of the timed steps only, from pre-created event objects -- still inside the
+    # timed region, still every launch of those kernels in those steps.  When the steady state replays a hipGraph those
+    # sampled steps run eagerly (events cannot be wrapped around the nodes of a replayed graph).
     sampled = [False]
+    sample_steps = sorted({(j + 1) * args.steps // (EVENT_STEPS + 1) for j in range(EVENT_STEPS)}) if timed else []
     if timed:
-        _lib.PROFILE = {"hpcs_gemm_tn": [], "hpcs_hyphc_sampled": []}
-        _lib.PROFILE_FILTER = lambda name, tg: sampled[0] and (name != "hpcs_gemm_tn" or is_big_mfma_gemm(tg))
+        # (only the step's longest kernel gets its pair inside the timed region -- ONE pair per sampled step; the 14 launches of
+        # the big GEMM class are timed with the other secondary kernels in EXTRA_STEPS further steps after it: their 28
+        # barrier packets per step are what made the timed region slow and erratic)
+        _lib.PROFILE = {"hpcs_hyphc_sampled": []}
+        _lib.PROFILE_FILTER = lambda name, tg: sampled[0]
+        _lib.EVENT_POOL = [torch.cuda.Event(enable_timing=True) for _ in range(64 * max(len(sample_steps), 1))]
     kept_hist = []
     t0 = time.perf_counter()
     for i_step in range(args.steps):
-        sampled[0] = timed and (i_step % EVENT_EVERY) == 0
+        sampled[0] = i_step in sample_steps
         if sampled[0] and mode == "graph":
             losses = step._eager_step(pts_d, cat_d, tgt_d, tgt)
         else:
@@ -370,6 +376,7 @@ def main():
     torch.cuda.synchronize()
     prof, _lib.PROFILE = _lib.PROFILE, None
     _lib.PROFILE_FILTER = None
+    _lib.EVENT_POOL = None
     prof_extra = {}
     if timed:                  # every rank runs them: the step contains the gradient all-reduce
         # the secondary kernels (EdgeConv GEMM, kNN) are timed in EXTRA_STEPS further EAGER steps OUTSIDE the timed
@@ -464,18 +471,17 @@ def main():
     if timed and prof:
         def dur(lst):
             return [(e0.elapsed_time(e1) * 1e-3, tag) for e0, e1, tag in lst]
-        n_sampled = len(range(0, args.steps, EVENT_EVERY))
+        n_sampled = max(len(sample_steps), 1)
         step_s = dt / args.steps
-        gm = dur(prof["hpcs_gemm_tn"])
         hb = dur(prof["hpcs_hyphc_sampled"])
         kn = dur(prof_extra["hpcs_knn"])
         gm_extra = dur(prof_extra["hpcs_gemm_tn"])
-        big = [(d, t_) for d, t_ in gm if is_big_mfma_gemm(t_)]
+        big = [(d, t_) for d, t_ in gm_extra if is_big_mfma_gemm(t_)]
         small = [(d, t_) for d, t_ in gm_extra if t_[7] <= 64 and not is_small_gemm(t_)]
         gm_flops = sum(gemm_flops(t_) for _, t_ in big)
         gm_time = sum(d for d, _ in big)
         hb_time = sum(d for d, _ in hb)
-        rank_gemm = 1 if gm_time >= hb_time else 2
+        rank_gemm = 1 if gm_time / EXTRA_STEPS >= hb_time / n_sampled else 2
         gemm_obj = {"kernel": "gemm_tn_kernel<128,128,16,2,2> (hpcs_gemm_tn, M > 64: VN dense layers + heads, forward and "
                               "data-grad)",
                     "bound": "mfma", "achieved": round(gm_flops / gm_time / 1e12, 3), "peak": MFMA_F32_PEAK_TF,
@@ -483,11 +489,9 @@ def main():
                     "traffic": pmc_traffic("gemm_tn_kernel<128"),
                     "algorithmic_bytes_per_launch": round(sum(gemm_bytes(t_) for _, t_ in big) / len(big)),
                     "launches": len(big), "avg_launch_us": round(1e6 * gm_time / len(big), 2),
-                    "share_of_step": round(gm_time / (step_s * n_sampled), 4),
+                    "share_of_step": round(gm_time / (step_s * EXTRA_STEPS), 4),
                     "rank_by_time": rank_gemm,
-                    "measured": f"HIP events around every launch of the kernel in every {EVENT_EVERY}th step of "
-                                "the timed region" + (" (those steps run eagerly; the others replay the hipGraph)"
-                                                      if mode == "graph" else "")}
+                    "measured": EXTRA_NOTE}
         hyphc_obj = None
         if hb:
             E_ = args.embedding
@@ -514,7 +518,7 @@ def main():
                          "l2_gather": {"gathered_bytes_per_launch": l2_bytes, "achieved_GBs": round(l2_bytes / avg / 1e9, 1),
                                        "peak_GBs": L2_GATHER_PEAK_GBS, "frac": round(l2_bytes / avg / 1e9 / L2_GATHER_PEAK_GBS, 4)},
                          "measured": "HIP events around the entry point (one zero-fill launch + the kernel) in "
-                                     f"every {EVENT_EVERY}th step of the timed region",
+                                     f"{len(sample_steps)} of the {args.steps} steps of the timed region",
                          "note": "`achieved` follows SURVEY 8(d)'s algorithmic bytes against the HBM line as the bench contract "
                                  "asks; the kernel's real ceiling is `binding_ceiling`"}
         # `roofline` = the kernel with the largest share of the step; the other one keeps its own key

@@ -105,6 +105,7 @@ def _dev_ptr(t):
 # PROFILE = {"hpcs_knn": [(start_event, end_event, tag), ...], ...}; only names present as keys are timed.
 PROFILE = None
 PROFILE_FILTER = None      # optional callable(name, shape_tag) -> bool: time only the launches it accepts
+EVENT_POOL = None          # optional list of pre-created timing events (popped; creating them inside a timed loop perturbs it)
 
 
 class Watch:
@@ -166,7 +167,10 @@ def call(name, *args, tag=None):
     if PROFILE is not None and name in PROFILE:
         tg = tag if tag is not None else _shape_tag(name, args)
         if PROFILE_FILTER is None or PROFILE_FILTER(name, tg):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            if EVENT_POOL is not None and len(EVENT_POOL) >= 2:
+                e0, e1 = EVENT_POOL.pop(), EVENT_POOL.pop()
+            else:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             rc = _call(name, *args)
             e1.record()

@@ -338,7 +338,10 @@ class HypHCStep(torch.nn.Module):
             return "eager_timed"
         ms = {f"graph_{f}": min(t[f"graph_{f}"]) for f in forms if t[f"graph_{f}"]}
         ms["eager"] = min(t["eager"])
-        best = min(ms, key=ms.get)
+        # a replayed step costs the host ~1.4 ms, the eager one 4-6 ms of a ~11 ms step: host jitter (a cold page cache, a busy
+        # core) shows in the eager step only (r03: 10.9 ... 13.7 ms run to run on one box), so a capture within 2 % of the
+        # eager step's best time is preferred
+        best = min(ms, key=lambda k_: ms[k_] * (1.02 if k_ == "eager" else 1.0))
         t["measured_ms"] = ms
         if best == "eager":
             t["choice"] = "eager"
