@@ -108,8 +108,9 @@ class VNLinearLeakyReLU(nn.Module):                            # vn_layers.py:48
     def forward_graph(self, feat, idx, pool_k=0):
         """forward(get_graph_feature(feat, idx=idx), pool_k) with the same forward arithmetic and a point-level backward
         (ops.VNGraphLayerFn): no edge-level data-gradient / weight-gradient GEMM, no scatter of an edge-sized gradient."""
-        if self.map_to_dir.weight.shape[0] == 1:
-            raise NotImplementedError("shared non-linearity is not used by the EdgeConv layers")
+        if self.map_to_dir.weight.shape[0] == 1:             # shared direction: the generic layer on the materialised edge tensor
+            from .vn_dgcnn_util import get_graph_feature
+            return self.forward(get_graph_feature(feat, k=idx.shape[-1], idx=idx), pool_k=pool_k)
         bn = self.batchnorm.bn
         out = ops.vn_graph_layer(feat, idx, self.map_to_feat.weight, self.map_to_dir.weight, bn.weight, bn.bias,
                                  bn.running_mean, bn.running_var, self.training, slope=self.negative_slope, pool_k=pool_k)
@@ -121,7 +122,8 @@ class VNLinearLeakyReLU(nn.Module):                            # vn_layers.py:48
         """Equivalent to forward(get_graph_feature(feat, idx=idx)) [then mean over k if pool], computed from the
         point features: no [B,2C,3,N,k] edge tensor, and a channel GEMM k times smaller (ops.VNEdgeLayerFn)."""
         if self.map_to_dir.weight.shape[0] == 1:
-            raise NotImplementedError("shared non-linearity is not used by the EdgeConv layers")
+            from .vn_dgcnn_util import get_graph_feature
+            return self.forward(get_graph_feature(feat, k=idx.shape[-1], idx=idx), pool_k=idx.shape[-1] if pool else 0)
         bn = self.batchnorm.bn
         out = ops.vn_edge_layer(feat, idx, self.map_to_feat.weight, self.map_to_dir.weight, bn.weight, bn.bias,
                                 bn.running_mean, bn.running_var, self.training, slope=self.negative_slope, pool=pool)
@@ -150,17 +152,15 @@ def mean_pool(x, dim=-1, keepdim=False):                       # vn_layers.py:15
 class VNStdFeature(nn.Module):                                 # vn_layers.py:156-205
     def __init__(self, in_channels, dim=4, normalize_frame=False, share_nonlinearity=False, negative_slope=0.2):
         super().__init__()
-        if normalize_frame:
-            raise NotImplementedError("normalize_frame=True is never used on the HPCS path (vn_dgcnn_partseg.py:39)")
-        if dim != 4:
-            raise NotImplementedError("only dim=4 is used on the HPCS path")
+        if dim not in (3, 4, 5):
+            raise ValueError("VNStdFeature: dim must be 3, 4 or 5 (vn_layers.py:197-202)")
         self.dim = dim
         self.normalize_frame = normalize_frame
         self.vn1 = VNLinearLeakyReLU(in_channels, in_channels // 2, dim=dim, share_nonlinearity=share_nonlinearity,
                                      negative_slope=negative_slope)
         self.vn2 = VNLinearLeakyReLU(in_channels // 2, in_channels // 4, dim=dim, share_nonlinearity=share_nonlinearity,
                                      negative_slope=negative_slope)
-        self.vn_lin = nn.Linear(in_channels // 4, 3, bias=False)
+        self.vn_lin = nn.Linear(in_channels // 4, 2 if normalize_frame else 3, bias=False)
 
     def frame(self, x, xconst=None, hub=None):
         """xconst: the N-constant half of vn1's input (tensor), or "mean": vn1 forms it as the mean of x over the
@@ -170,10 +170,24 @@ class VNStdFeature(nn.Module):                                 # vn_layers.py:15
         if isinstance(xconst, str):
             h, xmean = h
         z = self.vn2(h)
-        z = ops.chan_mix(z, self.vn_lin.weight, sink=(self.vn_lin.weight, ...))        # [B,3,3,N]
-        z0 = z.transpose(1, 2).contiguous()
+        z = ops.chan_mix(z, self.vn_lin.weight, sink=(self.vn_lin.weight, ...))        # [B, 3 (or 2), 3, *S]
+        if self.normalize_frame:
+            # Gram-Schmidt of the two predicted vectors + their cross product (vn_layers.py:180-193): a handful of
+            # device ops on [B,3,*S] tensors -- off the HPCS path (vn_dgcnn_partseg.py:39 builds normalize_frame=False)
+            v1 = z[:, 0]
+            u1 = v1 / (torch.sqrt((v1 * v1).sum(1, keepdim=True)) + 1e-6)
+            v2 = z[:, 1]
+            v2 = v2 - (v2 * u1).sum(1, keepdim=True) * u1
+            u2 = v2 / (torch.sqrt((v2 * v2).sum(1, keepdim=True)) + 1e-6)
+            u3 = torch.cross(u1, u2, dim=1)
+            z0 = torch.stack([u1, u2, u3], dim=1).transpose(1, 2).contiguous()
+        else:
+            z0 = z.transpose(1, 2).contiguous()
         return z0 if xmean is None else (z0, xmean)
 
     def forward(self, x):
         z0 = self.frame(x)
-        return ops.FrameProjectFn.apply(x, z0), z0
+        B, C = x.shape[0], x.shape[1]
+        # einsum('bij...,bjk...->bik...') for dim 3 / 4 / 5: the positions are one flattened axis for the kernel
+        x_std = ops.FrameProjectFn.apply(x.reshape(B, C, 3, -1), z0.reshape(B, 3, 3, -1)).reshape(x.shape)
+        return x_std, z0
