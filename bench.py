@@ -260,6 +260,8 @@ def main():
     ap.add_argument("--num-categories", type=int, default=None)
     ap.add_argument("--hierarchical", action="store_true", default=None,
                     help="PartNet-style hierarchical CosFace (configs 3 / 5)")
+    ap.add_argument("--settle-min", type=int, default=30,
+                    help="the settle rule may not fire before this many settle steps (the kept count is flat at first)")
     ap.add_argument("--settle-max", type=int, default=80,
                     help="upper bound of the untimed steps run until the miner's kept-triplet count is steady")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -310,17 +312,16 @@ def main():
     def one_step():
         return step.training_step(pts_d, cat_d, tgt_d, targets_host=tgt)
 
+    # Order: warm-up, settle, THEN the step's auto mode (capture forms against eager), so that the mode is chosen on the
+    # workload the timed region runs (r03: chosen on the pre-ramp workload, a replay that had measured 1.5 % ahead of eager
+    # ran the settled steps 3-4 % behind it).  The step's own eager warm-up count is held off until the settle is done.
+    hold_warmup, step.graph_warmup = step.graph_warmup, 1 << 30
     for _ in range(args.warmup):
         one_step()
-    n_tune = 0
-    while step.graph_mode() is None and n_tune < 20:      # auto mode: capture + timing of replay against eager (untimed)
-        one_step()
-        n_tune += 1
-    mode = step.graph_mode() or "eager"
-    mode_label = f"graph captured {step.graph_variant()}" if mode == "graph" else mode
-    # Steady state: training lets more triplets through the miner's filter for the first ~30-60 steps (8.2 M -> 13 M kept
-    # of 16.9 M at config 2), and the loss kernel's time follows; the timed region starts once the kept count moves by less
-    # than 1 % over 5 steps (or after SETTLE_MAX steps).  Untimed, reported; every rank runs the same number of steps.
+    # Steady state: training lets more triplets through the miner's filter between about step 15 and step 40 (8.2 M -> 13 M
+    # kept of 16.9 M at config 2; flat before that), and the loss kernel's time follows; the timed region starts once the
+    # kept count has moved by less than 1 % over 5 steps, no earlier than SETTLE_MIN steps in (the flat start satisfies the
+    # 1 % rule too) and no later than SETTLE_MAX.  Untimed, reported; every rank runs the same number of steps.
     n_settle, prev_kept, settle_hist = 0, None, []
     while n_settle < args.settle_max:
         for _ in range(5):
@@ -328,7 +329,8 @@ def main():
         n_settle += 5
         kept_now = float(step.metric_hyp_loss.last_kept.item())
         settle_hist.append(int(kept_now))
-        done = prev_kept is not None and abs(kept_now - prev_kept) <= 0.01 * max(kept_now, 1.0)
+        done = (prev_kept is not None and abs(kept_now - prev_kept) <= 0.01 * max(kept_now, 1.0)
+                and n_settle >= min(args.settle_min, args.settle_max))
         prev_kept = kept_now
         if world > 1:
             flag = torch.tensor([1.0 if done else 0.0], device=device)
@@ -336,6 +338,13 @@ def main():
             done = bool(flag.item() > 0.5)
         if done:
             break
+    step.graph_warmup = hold_warmup                      # the eager steps run so far count towards it
+    n_tune = 0
+    while step.graph_mode() is None and n_tune < 24:      # auto mode: capture + timing of replay against eager (untimed)
+        one_step()
+        n_tune += 1
+    mode = step.graph_mode() or "eager"
+    mode_label = f"graph captured {step.graph_variant()}" if mode == "graph" else mode
     barrier()
     timed = not args.no_kernel_timing
     # HIP events (on the launch stream) around every launch of the two heaviest kernels, live in the timed region:
@@ -448,7 +457,7 @@ def main():
                                 + (f"; measured ms/step per candidate: {step._tune['measured_ms']}"
                                    if getattr(step, '_tune', None) and step._tune.get('measured_ms') else "") + ")",
                    "untimed_steps_before_the_timed_region": args.warmup + n_tune + n_settle,
-                   "steady_state": f"{n_settle} untimed settle steps after warm-up / mode tuning: kept triplets every 5 steps "
+                   "steady_state": f"{n_settle} untimed settle steps after warm-up, before mode tuning: kept triplets every 5 steps "
                                    f"{settle_hist} (timed region starts once they move < 1 % per 5 steps)",
                    "triplet_rng": "device counter RNG (statistically equivalent to the reference's CPU torch.randint)",
                    "metrics_in_step": "accuracy + IoU of the CosFace logits computed on device every step (base_hyp_hc.py:126-130), "
@@ -504,10 +513,11 @@ def main():
             alg = T_s * (3 * 4 * E_ + 3 * 8)
             atomic_floor_s = kept * 4.0 * E_ / 1.3e12
             l2_bytes = T_s * (2 * 4 * E_) + kept * (2 * 4 * E_)
-            hyphc_obj = {"kernel": "hyphc_sampled_kernel<4,true> (hpcs_hyphc_sampled: triplets generated in-kernel, miner "
+            hyphc_obj = {"kernel": ("hyphc_sampled_kernel<8,true>" if E_ == 64 else f"hyphc_sampled4_kernel<{E_ // 8},true>") +
+                                   " (hpcs_hyphc_sampled: triplets generated in-kernel, miner "
                                    "rule inline, loss + gradient in one sweep)",
                          "bound": "hbm", "achieved": round(alg / avg / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(alg / avg / 1e9 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("hyphc_sampled_kernel"),
+                         "frac": round(alg / avg / 1e9 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("hyphc_sampled"),
                          "algorithmic_bytes_per_launch": alg, "launches": len(hb), "avg_launch_us": round(1e6 * avg, 2),
                          "share_of_step": round(hb_time / (step_s * n_sampled), 4), "rank_by_time": 3 - rank_gemm,
                          "triplets_sampled": T_s, "triplets_kept": kept,

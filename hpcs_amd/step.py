@@ -17,6 +17,26 @@ from .optim import RAdam
 FORWARD_SIDE = __import__("os").environ.get("HPCS_FWD_SIDE", "1") != "0"      # A/B: graph transposes in the forward pass
 
 
+_GC_SETTLED = False
+
+
+def _gc_settle():
+    """Once per process, after the first few training steps: one full collection, then gc.freeze().  CPython's first
+    generation-2 collection after start-up walks every object the imports created (torch + numpy: ~270 k containers here,
+    40-100 ms measured) and lands within the first ~50 steps of a loop -- a host stall of 4-9 step times with the GPU idle
+    (r03: it was the 10.9 ... 16 ms run-to-run spread of 20-step measurements).  Freezing moves the objects alive now into
+    the permanent generation: later full collections only walk what training allocated since.  Collection itself stays on.
+    HPCS_GC_FREEZE=0 leaves the collector alone."""
+    global _GC_SETTLED
+    if _GC_SETTLED:
+        return
+    _GC_SETTLED = True
+    if __import__("os").environ.get("HPCS_GC_FREEZE", "1") != "0":
+        import gc
+        gc.collect()
+        gc.freeze()
+
+
 def _watch_disarm(freeze=False):
     """Diagnostics (hpcs_amd/_lib.py Watch): the watch armed by class_metrics ends with the step; a capture's call list is
     kept (`freeze`) because replays execute exactly that list."""
@@ -109,6 +129,7 @@ class HypHCStep(torch.nn.Module):
         self._graph = None
         self._prep_cache = PrepCache()                 # rebuilt in configure() once the parameters are on the device
         self._eager_steps = 0
+        self._calls = 0
         self._tune = None                   # auto mode: {"phase", "t": {"eager": [...], "graph": [...]}, "ev"}
         self.metrics = True
         self.optimizer = None
@@ -294,6 +315,9 @@ class HypHCStep(torch.nn.Module):
         gradients on their side stream: a fork / join graph) and "serial" (one stream: a linear graph, cheaper per node
         for small clouds) -- and `HPCS_GRAPH=auto` times both against the eager step.  The losses returned by a replayed
         step are the capture's output tensors, overwritten by every replay."""
+        self._calls += 1
+        if self._calls == 4:
+            _gc_settle()
         if self._graph_eligible(targets_host, rot, drop_masks):
             if self._eager_steps >= self.graph_warmup:
                 if not self.graph_auto:
@@ -308,12 +332,15 @@ class HypHCStep(torch.nn.Module):
         return self._eager_step(points, label, targets, targets_host, rot, drop_masks)
 
     def _auto_mode(self):
-        """auto mode schedule after the warm-up, per candidate: capture + first replay (untimed), 2 timed replays -- first
-        the "side" form, then (that capture dropped: one private pool of activations at a time) the "serial" form -- then 2
-        timed eager steps; the fastest is kept for good (a winning "side" form is captured once more).  Times are event
-        spans of whole steps enqueued back to back.  The serial form was withdrawn in round 2 because its replays corrupted
-        the step's metric outputs; the cause was the runtime's handling of hipMemsetAsync NODES once a second graph exists
-        (DESIGN.md "The stray store"), and the library issues none any more."""
+        """auto mode schedule after the warm-up, per candidate: one lead-in step (for a capture form: the capture + its
+        first replay) and then a BURST of 3 steps enqueued back to back with no host wait in between, timed as one event
+        span from before the first to after the last -- what a training loop sees: the eager step's host work for step i+1
+        overlaps the GPU's step i (timing single steps between host waits charged the eager step its enqueue latency and
+        read both forms equal where the loop ran eager 3 % faster).  First the "side" form, then (that capture dropped: one
+        private pool of activations at a time) the "serial" form, then eager; the fastest is kept for good (a winning "side"
+        form is captured once more).  The serial form was withdrawn in round 2 because its replays corrupted the step's
+        metric outputs; the cause was the runtime's handling of hipMemsetAsync NODES once a second graph exists (DESIGN.md
+        "The stray store"), and the library issues none any more."""
         t = self._tune
         if t is None:
             t = self._tune = {"n": 0, "graph_side": [], "graph_serial": [], "eager": [], "pending": None, "choice": None}
@@ -322,19 +349,19 @@ class HypHCStep(torch.nn.Module):
         self._collect_timing()
         t["n"] += 1
         forms = self._candidate_forms()
-        per = 3
+        per = 4                                                           # lead-in + 3 timed
         if t["n"] <= per * len(forms):
             k, j = divmod(t["n"] - 1, per)
             if j == 0 and self._graph_form != forms[k]:
                 self._drop_graph()
             self._graph_form = forms[k]
-            t["kind"] = f"graph_{forms[k]}" if j > 0 else None            # replay 1 also pays the capture: not timed
+            t["kind"], t["pos"] = f"graph_{forms[k]}", (j, per)
             return "graph"
         if not self.use_graph:                                            # a capture failed: eager for good
             t["choice"] = "eager"
             return "eager"
-        if t["n"] <= per * len(forms) + 2:
-            t["kind"] = "eager"
+        if t["n"] <= per * (len(forms) + 1):
+            t["kind"], t["pos"] = "eager", (t["n"] - 1 - per * len(forms), per)
             return "eager_timed"
         ms = {f"graph_{f}": min(t[f"graph_{f}"]) for f in forms if t[f"graph_{f}"]}
         ms["eager"] = min(t["eager"])
@@ -382,19 +409,23 @@ class HypHCStep(torch.nn.Module):
     def _collect_timing(self):
         t = self._tune
         if t["pending"] is not None:
-            kind, e0, e1 = t["pending"]
+            kind, e0, e1, m = t["pending"]
             e1.synchronize()
-            if kind is not None:
-                t[kind].append(e0.elapsed_time(e1))
+            t[kind].append(e0.elapsed_time(e1) / m)
             t["pending"] = None
 
     def _timed(self, fn, *args):
+        """Steps 1 .. per-1 of a candidate's schedule form one timed burst (step 0 is its lead-in)."""
         t = self._tune
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+        j, per = t["pos"]
+        if j == 1:
+            t["e0"] = torch.cuda.Event(enable_timing=True)
+            t["e0"].record()
         out = fn(*args)
-        e1.record()
-        t["pending"] = (t.get("kind"), e0, e1)
+        if j == per - 1:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            t["pending"] = (t["kind"], t["e0"], e1, per - 1)
         return out
 
     # ---- host counters a step advances BEFORE its kernels run (restored when the step raises: ADVICE r2) -------------

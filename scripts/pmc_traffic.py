@@ -6,7 +6,10 @@ bytes of wide (16 B/lane) coalesced streaming reads -> doubled for kernels whose
 (listed in WIDE); WRITE_SIZE is exact for 16 B/lane streaming stores and float atomics.  Other access widths are
 uncalibrated and are reported uncorrected (flagged).
 
-usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [steps in the profiled run]
+usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [steps] [--last]
+  steps alone: the run held that many steps, all of them summarised;  with --last: only the LAST `steps` steps of the run are
+  summarised (dispatches after the (steps+1)-th launch from last of the once-per-step sampled HypHC kernel), which is how a
+  run that first settles to the steady workload is read on the steps the bench line times.
 """
 import collections
 import csv
@@ -21,16 +24,24 @@ WIDE = ("gemm_tn_kernel", "gemm_nt_kernel", "gemm_nt_edge_kernel", "_vec_kernel"
         "edge_segsum_kernel", "edge_gather_bwd_inv_kernel", "edge_grad_reduce_inv_kernel", "edge_grad_reduce_slab_kernel",
         "rowsum_wave_kernel", "rowsum_long_kernel", "vn_bwd_fused_kernel", "hpcs_zero_kernel")
 # 16 B/lane row GATHERS (random rows through L2): the x2 rule is calibrated for streaming reads only -> reported uncorrected
-GATHER = ("hyphc_sampled_kernel", "hyphc_kernel", "knn_mfma", "edge_gather_fwd_kernel")
+GATHER = ("hyphc_sampled", "hyphc_kernel", "knn_mfma", "edge_gather_fwd_kernel")
 
 
-def per_kernel(path, counter):
+def per_kernel(path, counter, last_steps=0):
     agg = collections.defaultdict(lambda: [0.0, 0])
     disp = collections.defaultdict(float)
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
-        disp[(r["Dispatch_Id"], r["Kernel_Name"])] += float(r["Counter_Value"])
+        disp[(int(r["Dispatch_Id"]), r["Kernel_Name"])] += float(r["Counter_Value"])
+    cut = -1
+    if last_steps:
+        marks = sorted(d for d, name in disp if "hyphc_sampled" in name)
+        if len(marks) < last_steps + 1:
+            raise SystemExit(f"{path}: only {len(marks)} steps in the run, cannot cut the last {last_steps}")
+        cut = marks[-last_steps - 1]
+        last = marks[-1]
+        disp = {k: v for k, v in disp.items() if cut < k[0] <= last}
     for (_, name), v in disp.items():
         agg[name][0] += v
         agg[name][1] += 1
@@ -43,8 +54,10 @@ def short(name):
 
 
 def main():
-    fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
-    write = per_kernel(sys.argv[2], "WRITE_SIZE")
+    steps = int(sys.argv[4]) if len(sys.argv) > 4 else None
+    last = steps if (len(sys.argv) > 5 and sys.argv[5] == "--last") else 0
+    fetch = per_kernel(sys.argv[1], "FETCH_SIZE", last)
+    write = per_kernel(sys.argv[2], "WRITE_SIZE", last)
     out = {}
     for name in sorted(set(fetch) | set(write), key=lambda n: -(fetch.get(n, [0, 1])[0] + write.get(n, [0, 1])[0])):
         f, nf = fetch.get(name, [0.0, 0])
@@ -56,9 +69,8 @@ def main():
         out[short(name)] = {"launches": n, "fetch_bytes_per_launch": round(fb / n), "write_bytes_per_launch": round(wb / n),
                             "hbm_bytes_per_launch": round((fb + wb) / n), "fetch_x2_correction": wide,
                             "fetch_uncalibrated_gather": any(t in name for t in GATHER)}
-    steps = int(sys.argv[4]) if len(sys.argv) > 4 else None
     total = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in out.values())
-    out["_total"] = {"hbm_bytes_all_launches": total, "steps_in_run": steps,
+    out["_total"] = {"hbm_bytes_all_launches": total, "steps_summarised": steps, "cut": "the last steps of a settled run" if last else "the whole run",
                      "hbm_bytes_per_step": round(total / steps) if steps else None,
                      "note": "FETCH_SIZE doubled for the kernels in WIDE (16 B/lane streaming reads); gathers uncorrected"}
     json.dump(out, open(sys.argv[3], "w"), indent=1)

@@ -2,7 +2,7 @@
 """Critical-path view of one training step from a rocprofv3 --kernel-trace CSV (the per-kernel averages of --stats add
 concurrent kernels' times together; with the weight-gradient GEMMs on a side stream that sum exceeds the wall time).
 
-  python3 scripts/timeline.py <kernel_trace.csv> [once-per-step kernel substring, default hyphc_sampled]
+  python3 scripts/timeline.py <kernel_trace.csv> [once-per-step kernel substring, default hyphc_sampled] [last N steps only]
 
 Steps are delimited by successive starts of the once-per-step kernel; reported per step (median over the steps found):
 wall, time with >=1 kernel running, time with >=2 running, idle time, and per kernel name the time during which it was the
@@ -48,7 +48,8 @@ def main():
             else: active.discard(j)
         steps.append({"wall": t1 - t0, "busy1": busy1, "busy2": busy2, "excl": excl, "tot": tot, "n": len(ks),
                       "queues": len({q for _, _, _, q in ks})})
-    steps = steps[len(steps) // 3:]                      # drop warm-up steps
+    last_n = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    steps = steps[-last_n:] if last_n else steps[len(steps) // 3:]      # steady-state tail, or just drop the warm-up steps
     med = lambda xs: sorted(xs)[len(xs) // 2]
     wall = med([s["wall"] for s in steps])
     print(f"steps analysed: {len(steps)}; queues: {steps[-1]['queues']}; launches/step: {steps[-1]['n']}")

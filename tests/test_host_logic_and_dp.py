@@ -92,3 +92,24 @@ def test_bucket_guards_against_detached_grads():
     lin.weight.grad = torch.zeros_like(lin.weight)      # what zero_grad(set_to_none=True)+backward would leave
     with pytest.raises(RuntimeError):
         b.zero()
+
+
+def test_gc_settle_runs_once_and_honours_the_switch(monkeypatch):
+    """hpcs_amd/step.py::_gc_settle: one collection + gc.freeze() per process (HPCS_GC_FREEZE=0: nothing)."""
+    import gc
+    from hpcs_amd import step as S
+    monkeypatch.setattr(S, "_GC_SETTLED", False)
+    monkeypatch.setenv("HPCS_GC_FREEZE", "0")
+    before = gc.get_freeze_count()
+    S._gc_settle()
+    assert gc.get_freeze_count() == before and S._GC_SETTLED
+    monkeypatch.setattr(S, "_GC_SETTLED", False)
+    monkeypatch.setenv("HPCS_GC_FREEZE", "1")
+    try:
+        S._gc_settle()
+        frozen = gc.get_freeze_count()
+        assert frozen > before
+        S._gc_settle()                                   # second call: no-op
+        assert gc.get_freeze_count() == frozen
+    finally:
+        gc.unfreeze()
