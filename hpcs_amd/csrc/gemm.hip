@@ -754,8 +754,17 @@ inline bool sr_two_level(int nsplit, int64_t ne) { return nsplit >= 256 && ne <=
 constexpr int NT_BKC = 32;      // 64-wide steps measured: +9 % on the HBM-bound EdgeConv shapes, -10 % on the large ones
 
 struct NtPlan { int tile, tilesM, tilesK, chunk, units_per_batch, nsplit; };
+static long nt_wg_target() {
+    static long v = [] {
+        const char* e = getenv("HPCS_NT_WG_TARGET");
+        long t = e ? atol(e) : 2048;
+        return t < 64 ? 64 : t;
+    }();
+    return v;
+}
 NtPlan nt_plan(int M, int Kx, int Nc, int n_batch) {
     NtPlan p;
+    const long WG = nt_wg_target();
     p.tile = (M > 512 && Kx > 512) ? 128 : 64;     // measured: 128x128 tiles only pay for the 682x682 layer
     p.tilesM = hpcs_cdiv(M, p.tile);
     p.tilesK = hpcs_cdiv(Kx, p.tile);
@@ -769,8 +778,8 @@ NtPlan nt_plan(int M, int Kx, int Nc, int n_batch) {
         const long tiles = (long)p.tilesM * p.tilesK;
         const long units0 = (long)n_batch * hpcs_cdiv(Nc, p.chunk);
         const long split_cap = (8L << 20) / ((long)M * Kx);              // partial buffer <= 32 MB
-        if (units0 * tiles < 1536 && split_cap > units0) {
-            long target_units = 2048 / tiles > 0 ? 2048 / tiles : 1;
+        if (units0 * tiles < WG * 3 / 4 && split_cap > units0) {
+            long target_units = WG / tiles > 0 ? WG / tiles : 1;
             if (target_units > split_cap) target_units = split_cap;
             long c = hpcs_cdiv((int64_t)Nc * n_batch, target_units);
             c = (c + 31) / 32 * 32;
@@ -780,7 +789,7 @@ NtPlan nt_plan(int M, int Kx, int Nc, int n_batch) {
     }
     p.units_per_batch = hpcs_cdiv(Nc, p.chunk);
     const long units = (long)n_batch * p.units_per_batch;
-    long want = 2048 / ((long)p.tilesM * p.tilesK);
+    long want = WG / ((long)p.tilesM * p.tilesK);
     if (want < 1) want = 1;
     p.nsplit = (int)(units < want ? units : want);
     if (p.nsplit < 1) p.nsplit = 1;

@@ -596,6 +596,33 @@ __global__ __launch_bounds__(TPB) void hyphc_kernel(const float* __restrict__ xn
 // Positive rows belong to the anchor's class: their gradients accumulate in an LDS table indexed by the member's
 // rank (ds_add_f32) and are flushed once per workgroup -- ~10x fewer global atomics than one per triplet; negative
 // rows are random over the cloud and use the row-contiguous global atomic shape.
+// Float add into an LDS table, EPL elements at stride SUB.  NOT ds_add_f32: on gfx950 that instruction retires one LANE per
+// 3 cycles -- 193 cycles per 64-lane wave-instruction whatever the addresses, against 5.5 for ds_add_u32 and 17 for this
+// compare-and-swap loop (scratch microbenchmark, r03: 16 waves per CU, the table's access pattern).  The positive table's
+// 8.2 M ds_add_f32 per launch were 2.5 ms of LDS-pipe time per CU in a 2.9 ms kernel (SQ_LDS_IDX_ACTIVE = 73 % of the
+// kernel's cycles; "87 % of the wait cycles are LDS waits").  All EPL reads, then all EPL swaps, are in flight together;
+// a lane whose swap lost (two groups of the wave-instruction on one row) retries that element only.
+template <int EPL>
+__device__ __forceinline__ void lds_add_row(float* base, const float (&v)[EPL]) {
+    int* ip = reinterpret_cast<int*>(base);
+    int cur[EPL];
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) cur[j] = ip[j * SUB];
+    unsigned pending = (1u << EPL) - 1u;
+    do {
+        int got[EPL];
+#pragma unroll
+        for (int j = 0; j < EPL; ++j)
+            if ((pending >> j) & 1u) got[j] = atomicCAS(ip + j * SUB, cur[j], __float_as_int(__int_as_float(cur[j]) + v[j]));
+#pragma unroll
+        for (int j = 0; j < EPL; ++j)
+            if ((pending >> j) & 1u) {
+                if (got[j] == cur[j]) pending &= ~(1u << j);
+                else cur[j] = got[j];
+            }
+    } while (pending);
+}
+
 constexpr int SB_THREADS = 1024;
 constexpr int SB_GROUPS = SB_THREADS / SUB;      // 128
 constexpr int SB_SEG_MAX = 128;                  // triplets per 8-lane group: chosen per launch (multiple of 8) so that the
@@ -834,8 +861,10 @@ __global__ __launch_bounds__(SB_THREADS) void hyphc_sampled_kernel(
                     for (int j = 0; j < EPL; ++j) acc_a[j] += c0 * pv[j] + c1 * nv[j];
                     // positive row: LDS table of the workgroup's class, else straight to memory
                     if (cpos >= 0) {
+                        float gp[EPL];
 #pragma unroll
-                        for (int j = 0; j < EPL; ++j) atomicAdd(cache + cpos * TS + j * SUB + s, c0 * av[j] + c2 * nv[j]);
+                        for (int j = 0; j < EPL; ++j) gp[j] = c0 * av[j] + c2 * nv[j];
+                        lds_add_row<EPL>(cache + cpos * TS + s, gp);
                     } else {
 #pragma unroll
                         for (int j = 0; j < EPL; ++j) atomicAdd(gxn + (unsigned)(ip * E + s * EPL + j), c0 * av[j] + c2 * nv[j]);
@@ -1125,12 +1154,13 @@ __global__ __launch_bounds__(SB_THREADS) void hyphc_sampled4_kernel(
                         qn -= 8;
                     }
                 }
-                // positive row LAST: LDS executes in order, so the ring's reads above would otherwise wait behind these
-                // (slow) ds_add_f32 -- 87 % of the kernel's wait cycles are LDS waits (PMC, r03)
+                // positive row last (LDS executes in order per wave: the ring's reads above do not queue behind the table update)
                 if (lv) {
                     if (cpos >= 0) {
+                        float gp[EPL];
 #pragma unroll
-                        for (int j = 0; j < EPL; ++j) atomicAdd(cache + cpos * TS + j * SUB + s, c0 * av[j] + c2 * Ng[q][j]);
+                        for (int j = 0; j < EPL; ++j) gp[j] = c0 * av[j] + c2 * Ng[q][j];
+                        lds_add_row<EPL>(cache + cpos * TS + s, gp);
                     } else {
 #pragma unroll
                         for (int j = 0; j < EPL; ++j) atomicAdd(gxn + (unsigned)(ip * E + s * EPL + j), c0 * av[j] + c2 * Ng[q][j]);
