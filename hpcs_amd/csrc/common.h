@@ -58,6 +58,22 @@ static inline int hpcs_zero_async(hipStream_t st, void* p0, size_t n0, void* p1 
     return e == hipSuccess ? HPCS_OK : HPCS_ERR_HIP - (int)e;
 }
 
+// Strided form: `rows` blocks of `width` floats, `pitch` floats apart (the shared-direction gradient block of every cloud of
+// a [B, Cout + 1, 3, L] tensor).  Same reason: hipMemset2DAsync is a memset node as well.
+static __global__ void hpcs_zero_rows_kernel(float* __restrict__ p, size_t pitch, size_t width) {
+    float* q = p + (size_t)blockIdx.y * pitch;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < width; i += (size_t)gridDim.x * blockDim.x) q[i] = 0.f;
+}
+static inline int hpcs_zero_rows_async(hipStream_t st, float* p, size_t pitch, size_t width, int rows) {
+    if (rows <= 0 || width == 0) return HPCS_OK;
+    if (rows > 65535) return HPCS_ERR_SHAPE;
+    long bx = (long)((width + 1023) / 1024);
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(hpcs_zero_rows_kernel, dim3((unsigned)bx, (unsigned)rows), dim3(256), 0, st, p, pitch, width);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? HPCS_OK : HPCS_ERR_HIP - (int)e;
+}
+
 // Bijective XCD-aware block remap (cdna_hip_programming.md T1): hardware deals consecutive
 // block ids round-robin over the 8 XCDs; give each XCD a contiguous run of logical ids so that
 // neighbouring tiles (which share operand panels) hit the same L2.

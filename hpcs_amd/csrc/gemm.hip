@@ -460,6 +460,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(
     float (*Gs)[LD] = reinterpret_cast<float (*)[LD]>(sm_all);
     float (*Xs)[LD] = reinterpret_cast<float (*)[LD]>(sm_all + BM * LD);
 
+    // (Measured and NOT kept, r03: hpcs_xcd_remap here, so that the tiles of one split -- which read the same column slice of
+    // G and X -- share one XCD's L2: the 340 x 341 / 682 x 341 gradients went 379 -> 603 us and 649 -> 698 us standalone.)
     const int tile = blockIdx.x % (tilesM * tilesK);
     const int split = blockIdx.x / (tilesM * tilesK);
     const int rowTile = tile % tilesM, colTile = tile / tilesM;

@@ -2308,9 +2308,7 @@ static int vn_bwd_apply_impl(PdRef pd, const float* gout, const float* mean, con
         const int Ctot = Cout + Cd;
         const int chunks = Cout < 16 ? Cout : 16, c_chunk = hpcs_cdiv(Cout, chunks);
         // zero the B direction blocks [3][L] (row pitch Ctot*3*L floats) that the channel chunks add into
-        if (hipMemset2DAsync(GPD + (int64_t)Cout * 3 * L, sizeof(float) * (size_t)Ctot * 3 * L, 0, sizeof(float) * 3 * (size_t)L, B,
-                             st) != hipSuccess)
-            return HPCS_ERR_HIP;
+        if (const int zr = hpcs_zero_rows_async(st, GPD + (int64_t)Cout * 3 * L, (size_t)Ctot * 3 * L, 3 * (size_t)L, B)) return zr;
         if (pd_materialised(pd) && pool_k == 0 && L % 4 == 0 && B <= 65535 &&
             ((((uintptr_t)pd.base | (uintptr_t)gout | (uintptr_t)GPD) & 15u) == 0)) {
             // enough channel chunks to put >= ~1500 workgroups on the chip, at least 4 channels each
