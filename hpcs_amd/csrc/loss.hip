@@ -605,22 +605,27 @@ __global__ __launch_bounds__(TPB) void hyphc_kernel(const float* __restrict__ xn
 template <int EPL>
 __device__ __forceinline__ void lds_add_row(float* base, const float (&v)[EPL]) {
     int* ip = reinterpret_cast<int*>(base);
-    int cur[EPL];
+    int cur[EPL], got[EPL];
 #pragma unroll
     for (int j = 0; j < EPL; ++j) cur[j] = ip[j * SUB];
-    unsigned pending = (1u << EPL) - 1u;
-    do {
-        int got[EPL];
 #pragma unroll
-        for (int j = 0; j < EPL; ++j)
-            if ((pending >> j) & 1u) got[j] = atomicCAS(ip + j * SUB, cur[j], __float_as_int(__int_as_float(cur[j]) + v[j]));
+    for (int j = 0; j < EPL; ++j) got[j] = atomicCAS(ip + j * SUB, cur[j], __float_as_int(__int_as_float(cur[j]) + v[j]));
+    bool lost = false;
 #pragma unroll
-        for (int j = 0; j < EPL; ++j)
-            if ((pending >> j) & 1u) {
-                if (got[j] == cur[j]) pending &= ~(1u << j);
-                else cur[j] = got[j];
+    for (int j = 0; j < EPL; ++j) lost = lost || (got[j] != cur[j]);
+    if (lost) {                       // rare (< 1 % of the updates): straight-line code above, the retries out of line
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+            int seen = got[j];
+            if (seen != cur[j]) {
+                int expect;
+                do {
+                    expect = seen;
+                    seen = atomicCAS(ip + j * SUB, expect, __float_as_int(__int_as_float(expect) + v[j]));
+                } while (seen != expect);
             }
-    } while (pending);
+        }
+    }
 }
 
 constexpr int SB_THREADS = 1024;
@@ -797,10 +802,11 @@ __global__ __launch_bounds__(SB_THREADS) void hyphc_sampled_kernel(
         const float e0 = __expf(q0 - mx), e1 = __expf(q1 - mx), e2 = __expf(q2 - mx);
         const float w0 = 0.5f * (1.f + D1), w1 = 0.5f * (1.f + D2), w2 = 0.5f * (1.f + D3);
         const float den = e0 + e1 + e2;
-        const float wbar = (e0 * w0 + e1 * w1 + e2 * w2) / den;
+        const float inv_den = fast_rcp(den);                          // v_rcp_f32 (1 ulp) once, not four IEEE divisions
+        const float wbar = (e0 * w0 + e1 * w1 + e2 * w2) * inv_den;
         if (live) acc_loss += (double)((w0 + w1 + w2) - wbar);
         if (GRAD) {
-            const float sm0 = e0 / den, sm1 = e1 / den, sm2 = e2 / den;
+            const float sm0 = e0 * inv_den, sm1 = e1 * inv_den, sm2 = e2 * inv_den;
             const float gd0 = -(sm0 * (w0 - wbar)) * inv_t, gd1 = -(sm1 * (w1 - wbar)) * inv_t,
                         gd2 = -(sm2 * (w2 - wbar)) * inv_t;
             // unscaled weights of the three similarity gradients: upstream/kept are applied later
@@ -1036,7 +1042,21 @@ __global__ __launch_bounds__(SB_THREADS) void hyphc_sampled4_kernel(
             if (c_t1 > c_t0) { c_k = cls_k[c]; c_off = offsets[c]; c_na = offsets[c + 1] - c_off; }
         }
         const unsigned kq = (unsigned)(c_k > 0 ? c_k : 1);
-        const int rank = (int)((unsigned)(tt - c_t0) / kq);
+        // anchor rank = (t - t0_c) / k_c.  A class with fewer than 2^24 triplets: float reciprocal + one correction step
+        // (x is exact in fp32, the quotient estimate is off by at most one) instead of the ~25-instruction 32-bit division
+        int rank;
+        {
+            const unsigned x = (unsigned)(tt - c_t0);
+            if ((unsigned)(c_t1 - c_t0) < (1u << 24) && kq < (1u << 24)) {
+                unsigned qd = (unsigned)((float)x * fast_rcp((float)kq));
+                const int rem = (int)(x - __umul24(qd, kq));
+                qd += rem >= (int)kq ? 1u : 0u;
+                qd -= rem < 0 ? 1u : 0u;
+                rank = (int)qd;
+            } else {
+                rank = (int)(x / kq);
+            }
+        }
         const int ia_own = order[c_off + rank];
         const unsigned hp = hash32((unsigned)tt ^ seed_lo, seed_hi);          // (tt >> 32) == 0: the r02 kernel's stream
         const int rp = (int)__umulhi(hp, (unsigned)(c_na > 1 ? c_na - 1 : 1));
@@ -1096,10 +1116,11 @@ __global__ __launch_bounds__(SB_THREADS) void hyphc_sampled4_kernel(
         const float e0 = __expf(q0 - mx), e1 = __expf(q1 - mx), e2 = __expf(q2 - mx);
         const float w0 = 0.5f * (1.f + D1), w1 = 0.5f * (1.f + D2), w2 = 0.5f * (1.f + D3);
         const float den = e0 + e1 + e2;
-        const float wbar = (e0 * w0 + e1 * w1 + e2 * w2) / den;
+        const float inv_den = fast_rcp(den);                          // v_rcp_f32 (1 ulp) once, not four IEEE divisions
+        const float wbar = (e0 * w0 + e1 * w1 + e2 * w2) * inv_den;
         if (live && owner) acc_loss += (double)((w0 + w1 + w2) - wbar);
         if (GRAD) {
-            const float sm0 = e0 / den, sm1 = e1 / den, sm2 = e2 / den;
+            const float sm0 = e0 * inv_den, sm1 = e1 * inv_den, sm2 = e2 * inv_den;
             const float gd0 = -(sm0 * (w0 - wbar)) * inv_t, gd1 = -(sm1 * (w1 - wbar)) * inv_t,
                         gd2 = -(sm2 * (w2 - wbar)) * inv_t;
             const float c0_own = 0.5f * ((1.f - sm0) + gd0 * L1.dd_dw), c1_own = 0.5f * ((1.f - sm1) + gd1 * L2.dd_dw),
