@@ -613,7 +613,7 @@ __device__ __forceinline__ void lds_add_row(float* base, const float (&v)[EPL]) 
     bool lost = false;
 #pragma unroll
     for (int j = 0; j < EPL; ++j) lost = lost || (got[j] != cur[j]);
-    if (lost) {                       // rare (< 1 % of the updates): straight-line code above, the retries out of line
+    if (__builtin_amdgcn_ballot_w64(lost) != 0ull && lost) {   // rare (< 1 % of the updates): wave-uniform test, retries out of line
 #pragma unroll
         for (int j = 0; j < EPL; ++j) {
             int seen = got[j];
@@ -1127,31 +1127,39 @@ __global__ __launch_bounds__(SB_THREADS) void hyphc_sampled4_kernel(
                         c2_own = 0.5f * ((1.f - sm2) + gd2 * L3.dd_dw);
             if (live && owner && s_live)
                 acc_gs += (double)(gd0 * L1.dd_ds) + (double)(gd1 * L2.dd_ds) + (double)(gd2 * L3.dd_ds);
-            // ---- phase C: row gradients from the rows still in registers
+            // ---- phase C: row gradients from the rows still in registers.  The kernel is instruction-issue bound (r03 PMC:
+            // some unit issues in 86 % of the cycles, four waves per SIMD), and a divergent `if` costs ~5 scalar
+            // instructions whether or not it is taken: dropped triplets carry ZERO coefficients instead of being branched
+            // around, and the rare events (anchor change, a positive outside the table, a lost swap) sit behind wave-uniform
+            // tests.
             const int cp_own = live ? cpos_own : -2;                        // -2: dropped triplet, -1: positive not tabled
+            const float c0_z = live ? c0_own : 0.f, c1_z = live ? c1_own : 0.f;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int cpos = BQ(cp_own, q);
                 const bool lv = cpos > -2;
-                const float c0 = BQ(c0_own, q), c1 = BQ(c1_own, q), c2 = BQ(c2_own, q);
-                const int ia = BQ(ia_own, q), ip = BQ(ip_own, q), in = BQ(in_own, q);
-                if (lv) {
-                    if (ia != ia_have) {                                    // (only when the anchor changed inside the batch)
-                        IO::load(xn, E, ia, s, av);
-                        ia_have = ia;
-                    }
-                    if (ia != cur) {
-                        if (cur >= 0) {
-#pragma unroll
-                            for (int j = 0; j < EPL; ++j) atomicAdd(gxn + (unsigned)(cur * E + s * EPL + j), acc_a[j]);
+                const float c0 = BQ(c0_z, q), c1 = BQ(c1_z, q), c2 = BQ(c2_own, q);
+                const int ia = BQ(ia_own, q), in = BQ(in_own, q);
+                const bool moved = lv && (ia != cur || ia != ia_have);
+                if (__builtin_amdgcn_ballot_w64(moved) != 0ull) {           // once per ~k_c triplets and group
+                    if (moved) {
+                        if (ia != ia_have) {                                // (the anchor changed inside the batch)
+                            IO::load(xn, E, ia, s, av);
+                            ia_have = ia;
                         }
-                        cur = ia;
+                        if (ia != cur) {
+                            if (cur >= 0) {
 #pragma unroll
-                        for (int j = 0; j < EPL; ++j) acc_a[j] = 0.f;
+                                for (int j = 0; j < EPL; ++j) atomicAdd(gxn + (unsigned)(cur * E + s * EPL + j), acc_a[j]);
+                            }
+                            cur = ia;
+#pragma unroll
+                            for (int j = 0; j < EPL; ++j) acc_a[j] = 0.f;
+                        }
                     }
-#pragma unroll
-                    for (int j = 0; j < EPL; ++j) acc_a[j] += c0 * P[q][j] + c1 * Ng[q][j];
                 }
+#pragma unroll
+                for (int j = 0; j < EPL; ++j) acc_a[j] += c0 * P[q][j] + c1 * Ng[q][j];     // zeros for a dropped triplet
                 {
                     const unsigned long long lbal = __ballot(lv);                 // all 8 lanes of a kept group are set
                     const int n_live = __popcll(lbal) >> 3;
@@ -1176,13 +1184,15 @@ __global__ __launch_bounds__(SB_THREADS) void hyphc_sampled4_kernel(
                     }
                 }
                 // positive row last (LDS executes in order per wave: the ring's reads above do not queue behind the table update)
-                if (lv) {
-                    if (cpos >= 0) {
-                        float gp[EPL];
+                if (cpos >= 0) {
+                    float gp[EPL];
 #pragma unroll
-                        for (int j = 0; j < EPL; ++j) gp[j] = c0 * av[j] + c2 * Ng[q][j];
-                        lds_add_row<EPL>(cache + cpos * TS + s, gp);
-                    } else {
+                    for (int j = 0; j < EPL; ++j) gp[j] = c0 * av[j] + c2 * Ng[q][j];
+                    lds_add_row<EPL>(cache + cpos * TS + s, gp);
+                }
+                if (__builtin_amdgcn_ballot_w64(cpos == -1) != 0ull) {      // a class larger than the table (rare)
+                    const int ip = BQ(ip_own, q);
+                    if (cpos == -1) {
 #pragma unroll
                         for (int j = 0; j < EPL; ++j) atomicAdd(gxn + (unsigned)(ip * E + s * EPL + j), c0 * av[j] + c2 * Ng[q][j]);
                     }
