@@ -764,6 +764,9 @@ static long nt_wg_target() {
     }();
     return v;
 }
+// (Measured and NOT kept, r03: capping this GEMM's residency with unused dynamic LDS -- 4 / 3 / 2 workgroups per CU instead of
+// 8 -- so that the main stream's streaming kernels find free wave slots next to it: 10.61 -> 10.55 / 10.53 / 10.58 ms per step,
+// i.e. nothing.  The side stream slows them through the memory system, not through occupancy.)
 NtPlan nt_plan(int M, int Kx, int Nc, int n_batch) {
     NtPlan p;
     const long WG = nt_wg_target();
