@@ -252,6 +252,123 @@ __global__ __launch_bounds__(WM* WN * 64, 4) void gemm_tn_kernel(
     tn_tile<BM, BN, BK, WM, WN, FAST>(At, lda, Bp, ldb, Cp, ldc, M, Nc, K, bias, accumulate, m0, n0, vecA, vecB, vecC, lds_raw);
 }
 
+// The EdgeConv channel mix of a graph layer with its edge tensor formed in the operand loader: PD[b] (M x 3*N*k) = At^T E[b],
+// E = get_graph_feature(feat, idx) (vn_dgcnn_util.py:10-37) -- row r < C is the difference channel x[r, a, idx[n, j]] - x[r, a, n],
+// row r >= C the centre channel x[r - C, a, n], column (a, n, j) = (a * N + n) * k + j -- and E never exists in memory.
+// One workgroup = one 64 x 128 output tile with the WHOLE reduction (K = 2C <= 64) staged at once.  The gathers read a
+// POINT-major copy of the features (featT [b][a][n][Cp], Cp = pad4(C): feat_transpose_kernel, 8 MB at B = 32): a thread owns
+// one column (one edge) and fetches FOUR channels of its neighbour / its centre per 16-byte load -- 12 loads per column.  (The
+// channel-major layout costs one 4-byte gather per element: 4032 scattered loads per tile, and the texture path resolves one
+// cache line per cycle -- that form measured 192-195 us whether the loads were issued per 16-deep step or all at once, against
+// 101 + 159 us for gather + GEMM.)  MFMA operand mapping and k order are those of tn_tile<64,128,..>, so the product is
+// bit-identical to hpcs_edge_gather_fwd + hpcs_gemm_tn.
+constexpr int GM_BM = 64, GM_BN = 128, GM_KMAX = 64;
+__global__ void feat_transpose_kernel(const float* __restrict__ feat, int C, int Cp, int N, float* __restrict__ featT) {
+    // feat [b][c][a][n] -> featT [b][a][n][Cp]; one thread per (a, n, 4 channels)
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int g4 = Cp / 4;
+    if (t >= 3 * N * g4) return;
+    const int g = t % g4, n = (t / g4) % N, a = t / (g4 * N);
+    const float* src = feat + (int64_t)b * C * 3 * N + (int64_t)a * N + n;
+    float v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = (4 * g + c < C) ? src[(int64_t)(4 * g + c) * 3 * N] : 0.f;
+    *reinterpret_cast<float4*>(featT + ((int64_t)b * 3 * N + (int64_t)a * N + n) * Cp + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
+}
+__global__ __launch_bounds__(256, 4) void gemm_tn_graph_kernel(
+    const float* __restrict__ At, int lda, const float* __restrict__ featT, const int64_t* __restrict__ idx, int C, int N, int k,
+    float* __restrict__ PD, int M, int tilesN, unsigned total) {
+    extern __shared__ __attribute__((aligned(16))) float gm_lds[];
+    const int K = 2 * C, Kp = (K + 1) & ~1, Cp = (C + 3) & ~3;
+    float (*As)[GM_BM] = reinterpret_cast<float (*)[GM_BM]>(gm_lds);                    // [Kp][64]
+    float (*Bs)[GM_BN] = reinterpret_cast<float (*)[GM_BN]>(gm_lds + Kp * GM_BM);       // [Kp][128]
+    const unsigned logical = hpcs_xcd_remap(blockIdx.x, total);
+    const int colTile = logical % tilesN;
+    const int b = logical / tilesN;
+    const int Nc = 3 * N * k, n0 = colTile * GM_BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // ---- B: thread = (column, half of the channel groups); a column is one edge (a, n, j)
+    const int cl = tid & 127, half = tid >> 7;
+    const int col = min(n0 + cl, Nc - 1);                     // (a clamped column is never stored)
+    const int e = col % (N * k);
+    const int a = col / (N * k), nctr = e / k;
+    const int nbr = (int)idx[(int64_t)b * N * k + e];
+    const float* base = featT + ((int64_t)b * 3 * N + (int64_t)a * N) * Cp;
+    constexpr int GMAX = GM_KMAX / 2 / 4 / 2;                 // channel groups per thread: <= 4 (C <= 32)
+    float4 vn[GMAX], vc[GMAX];
+#pragma unroll
+    for (int i = 0; i < GMAX; ++i) {
+        const int g = half + 2 * i;
+        vn[i] = vc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (4 * g < C) {
+            vn[i] = *reinterpret_cast<const float4*>(base + (int64_t)nbr * Cp + 4 * g);
+            vc[i] = *reinterpret_cast<const float4*>(base + (int64_t)nctr * Cp + 4 * g);
+        }
+    }
+    // ---- A: At [K][lda] -> As[k][m], zero beyond K / M (lda % 4 == 0, 16-byte aligned)
+    for (int f = tid; f < Kp * (GM_BM / 4); f += 256) {
+        const int kr = f / (GM_BM / 4), m4 = (f % (GM_BM / 4)) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kr < K && m4 < lda) v = *reinterpret_cast<const float4*>(At + (int64_t)kr * lda + m4);
+        *reinterpret_cast<float4*>(&As[kr][m4]) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < GMAX; ++i) {
+        const int g = half + 2 * i;
+        const float dn[4] = {vn[i].x - vc[i].x, vn[i].y - vc[i].y, vn[i].z - vc[i].z, vn[i].w - vc[i].w};
+        const float ct[4] = {vc[i].x, vc[i].y, vc[i].z, vc[i].w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int r = 4 * g + c;
+            if (r < C) {
+                Bs[r][cl] = dn[c];
+                Bs[C + r][cl] = ct[c];
+            }
+        }
+    }
+    if (Kp > K && half == 0) Bs[K][cl] = 0.f;                  // odd K: the padding row of the last k pair
+    __syncthreads();
+
+    // ---- 64 x 32 per wave: two 32 x 32 accumulators, the k order of tn_tile
+    const int lr = lane & 31, lk = lane >> 5;
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    for (int kk = 0; kk < Kp / 2; ++kk) {
+        const float bq = Bs[kk * 2 + lk][wave * 32 + lr];
+        const float a0 = As[kk * 2 + lk][lr], a1 = As[kk * 2 + lk][32 + lr];
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bq, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bq, acc[1], 0, 0, 0);
+    }
+    __syncthreads();                                          // operand tiles dead: their LDS becomes the transpose patches
+
+    // ---- epilogue: wave-private 32 x 36 patch, 16-byte row-contiguous stores (the shape that streams at the HBM rate)
+    constexpr int PP = 36;
+    float* patch = gm_lds + wave * (32 * PP);
+    float* Cb = PD + (int64_t)b * M * Nc;
+    const int col0 = n0 + wave * 32;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row0 = i * 32;
+        if (row0 >= M || col0 >= Nc) continue;                // wave-uniform
+#pragma unroll
+        for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * lk) * PP + lr] = acc[i][r];
+        __builtin_amdgcn_s_waitcnt(0xC07F);                   // lgkmcnt(0); the patch is wave-private
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int rr = it * 8 + (lane >> 3), c4 = (lane & 7) * 4;
+            const int row = row0 + rr, cc = col0 + c4;
+            if (row < M && cc + 3 < Nc)
+                *reinterpret_cast<float4*>(Cb + (int64_t)row * Nc + cc) = *reinterpret_cast<const float4*>(patch + rr * PP + c4);
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+    }
+}
+
 // Measured and NOT kept: the VN batch-norm statistics in this GEMM's epilogue for the EdgeConv layers (one workgroup computing
 // the same 64 x 128 tile of the x, y and z planes, |p| from the three accumulator sets): bit-identical product, 220 vs 254 us
 // against GEMM + statistics pass on cold data, but 185 vs 71 + 40 us inside the step (the statistics pass reads the
@@ -927,6 +1044,40 @@ extern "C" int hpcs_gemm_tn(const float* At, int lda, const float* Bm, int ldb, 
         else HPCS_TN_LAUNCH(64, 1, 4, false);
     }
 #undef HPCS_TN_LAUNCH
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
+extern "C" size_t hpcs_gemm_tn_graph_workspace(int B, int C, int N) {
+    if (B <= 0 || C <= 0 || N <= 0) return 0;
+    return (size_t)B * 3 * N * ((C + 3) & ~3) * sizeof(float);
+}
+
+extern "C" int hpcs_gemm_tn_graph(const float* At, int lda, const float* feat, const int64_t* idx, int B, int C, int N, int k,
+                                  int M, float* PD, void* ws, size_t ws_bytes, hpcs_stream_t stream) {
+    if (!At || !feat || !idx || !PD || !ws) return HPCS_ERR_NULL;
+    if (B < 0 || C <= 0 || N <= 0 || k <= 0 || M <= 0 || lda < M) return HPCS_ERR_SHAPE;
+    // the loader's assumptions: 16-byte pieces never straddle a point's neighbour list, straight-line (clamped) loads
+    if (M > GM_BM || 2 * C > GM_KMAX || k % 4 != 0 || lda % 4 != 0 || lda < 4 || !aligned16(At) || !aligned16(PD) ||
+        (int64_t)3 * N * k > 0x7fffffffL)
+        return HPCS_ERR_UNSUPPORTED;
+    if (B == 0) return HPCS_OK;
+    if (B > 65535 || ws_bytes < hpcs_gemm_tn_graph_workspace(B, C, N) || !aligned16(ws)) return HPCS_ERR_WORKSPACE;
+    const int Cp = (C + 3) & ~3;
+    float* featT = (float*)ws;
+    hipLaunchKernelGGL(feat_transpose_kernel, dim3((unsigned)hpcs_cdiv((long)3 * N * (Cp / 4), 256), (unsigned)B), dim3(256), 0,
+                       (hipStream_t)stream, feat, C, Cp, N, featT);
+    HPCS_CHECK_LAUNCH();
+    const int Nc = 3 * N * k;
+    const int tn = hpcs_cdiv(Nc, 128);
+    const long total = (long)tn * B;
+    if (total > 0x7fffffffL) return HPCS_ERR_UNSUPPORTED;
+    const int Kp = (2 * C + 1) & ~1;
+    size_t lds = (size_t)Kp * (GM_BM + GM_BN) * sizeof(float);
+    const size_t patches = (size_t)4 * 32 * 36 * sizeof(float);
+    if (lds < patches) lds = patches;
+    hipLaunchKernelGGL(gemm_tn_graph_kernel, dim3((unsigned)total), dim3(256), lds, (hipStream_t)stream, At, lda, featT, idx, C, N,
+                       k, PD, M, tn, (unsigned)total);
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;
 }

@@ -197,6 +197,7 @@ def gemm_WtG(W, G, nb, M, Nc, out=None, accumulate=False):
     return out
 
 
+GRAPH_GEMM = __import__("os").environ.get("HPCS_GRAPH_GEMM", "1") != "0"   # A/B: 0 = materialised edge tensor + plain GEMM
 NT_FUSED = __import__("os").environ.get("HPCS_NT_FUSED", "1") != "0"     # A/B: 0 = split partials summed by follow-up launches
 
 
@@ -807,15 +808,31 @@ class VNGraphLayerFn(torch.autograd.Function):
         Cout, Cd = Wf.shape[0], Wd.shape[0]
         Ctot = Cout + Cd
         dev = feat.device
-        E = torch.empty(B, 2 * C, 3, N, k, device=dev, dtype=torch.float32)
-        call("hpcs_edge_gather_fwd", feat, idx, B, C, N, k, E)
         WxP = PreparedW(Wf, Wd)
         flags = VN_BN | VN_LRELU
         mean = torch.empty(Cout, device=dev)
         rstd = torch.empty(Cout, device=dev)
         sums, ticket = _zeros64_ticket(2 * Cout, dev) if training else (None, None)
         k2 = C == 1 and K2_ON_THE_FLY
-        if k2:
+        # the channel mix with the edge tensor formed in its operand loader (hpcs_gemm_tn_graph: bit-identical product, no
+        # 330 MB edge tensor written and read back); otherwise the edge tensor is materialised for the plain GEMM
+        in_loader = GRAPH_GEMM and not k2 and Ctot <= 64 and 2 * C <= 64 and k % 4 == 0 and idx.dtype == torch.int64
+        E = None
+        if not in_loader:
+            E = torch.empty(B, 2 * C, 3, N, k, device=dev, dtype=torch.float32)
+            call("hpcs_edge_gather_fwd", feat, idx, B, C, N, k, E)
+        if in_loader:
+            Wm = _prep(WxP)
+            PD = torch.empty(B * Ctot * 3 * L, device=dev, dtype=torch.float32)
+            nbytes = call("hpcs_gemm_tn_graph_workspace", B, C, N)
+            ws = torch.empty(nbytes // 4, device=dev, dtype=torch.float32)
+            call("hpcs_gemm_tn_graph", Wm.At, Wm.At.shape[1], feat, idx, B, C, N, k, Ctot, PD, ws, nbytes)
+            if training and not _bn_fold(B * L):
+                call("hpcs_vn_norm_stats", PD, B, Cout, Ctot, L, sums, 1)
+                call("hpcs_bn_finalize", sums, Cout, B * L, BN_EPS, BN_MOMENTUM, rmean, rvar, mean, rstd, 1)
+            elif training:
+                call("hpcs_vn_norm_stats_finalize", PD, B, Cout, Ctot, L, sums, ticket, BN_EPS, BN_MOMENTUM, rmean, rvar, mean, rstd)
+        elif k2:
             # two input channels (conv1): PD = W E is two fmas per value -- formed inside the point-wise kernels from the
             # 16 MB edge tensor, bit-identical to the GEMM's chain, instead of a 330 MB tensor written once and read 4 times
             PD, ldw = E, WxP.Wp.shape[1]

@@ -87,6 +87,14 @@ typedef struct {
     int32_t ld1, M1, ld2, M2, K, lda, ldp, pad_;
 } hpcs_prep_desc;
 int hpcs_prep_weights_multi(const hpcs_prep_desc* desc_dev, int n, hpcs_stream_t stream);
+/* hpcs_gemm_tn_graph: PD[b] (M x 3*N*k) = At^T (M x 2C) @ E[b], E = get_graph_feature(feat, idx=idx) (vn_dgcnn_util.py:10-37:
+ * rows [0,C) = x_j - x_i, rows [C,2C) = x_i) formed inside the operand loader -- the [B,2C,3,N,k] edge tensor never exists in
+ * HBM.  Same values and the same k-ordered fma chain as hpcs_edge_gather_fwd followed by hpcs_gemm_tn (bit-identical output).
+ * feat [B,C,3,N], idx [B,N,k] int64 neighbour ids in [0,N); M <= 64, 2C <= 64, k % 4 == 0, lda % 4 == 0 (else
+ * HPCS_ERR_UNSUPPORTED). */
+size_t hpcs_gemm_tn_graph_workspace(int B, int C, int N);   /* bytes of `ws`: a point-major copy of feat */
+int hpcs_gemm_tn_graph(const float* At, int lda, const float* feat, const int64_t* idx, int B, int C, int N, int k, int M,
+                       float* PD, void* ws, size_t ws_bytes, hpcs_stream_t stream);
 size_t hpcs_gemm_nt_workspace(int M, int Kx, int Nc, int n_outer, int n_inner);
 /* hpcs_gemm_nt_fused: the same product with the split reduction INSIDE the launch (last-arriving workgroup per slice of
  * splits, then per tile; fixed summation order; no follow-up reduce launches).  `tickets`: hpcs_gemm_nt_tickets() int32

@@ -231,3 +231,48 @@ def test_row_linear_matches_fp64(R, K, M, ld):
     assert torch.allclose(vec.grad.double(), gv, rtol=1e-5, atol=1e-5 * float(gv.abs().max()))
     assert torch.allclose(Wfull.grad[:, ld - K:].double(), gw, rtol=1e-5, atol=1e-5 * float(gw.abs().max()))
     assert float(Wfull.grad[:, :ld - K].abs().max()) == 0.0 if ld > K else True
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,C,N,k,M", [(3, 21, 256, 20, 42), (2, 5, 96, 8, 10), (1, 21, 1024, 20, 42), (4, 32, 128, 4, 64), (3, 7, 200, 12, 3)])
+def test_gemm_tn_graph_equals_gather_then_gemm_bit_for_bit(B, C, N, k, M):
+    """hpcs_gemm_tn_graph (edge tensor formed in the operand loader) against hpcs_edge_gather_fwd + hpcs_gemm_tn: the same
+    values through the same k-ordered fma chain, so the outputs must be IDENTICAL (get_graph_feature, vn_dgcnn_util.py:10-37).
+    (Shapes with >= 32 tiles of 128 x 128: below that hpcs_gemm_tn takes its per-element kernel, another summation order.)"""
+    from hpcs_amd._lib import call
+    torch.manual_seed(B * 1000 + C)
+    dev = "cuda"
+    feat = torch.randn(B, C, 3, N, device=dev)
+    idx = torch.randint(0, N, (B, N, k), device=dev, dtype=torch.int64)
+    W = torch.randn(M, 2 * C, device=dev)
+    lda = (M + 3) // 4 * 4
+    At = torch.zeros(2 * C, lda, device=dev)
+    At[:, :M] = W.t()
+    L = N * k
+    E = torch.empty(B, 2 * C, 3, N, k, device=dev)
+    call("hpcs_edge_gather_fwd", feat, idx, B, C, N, k, E)
+    ref = torch.empty(B, M, 3 * L, device=dev)
+    call("hpcs_gemm_tn", At, lda, E, 3 * L, 2 * C * 3 * L, 0, ref, 3 * L, M * 3 * L, 0, M, 3 * L, 2 * C, B, 1, None, 0)
+    got = torch.full((B, M, 3 * L), float("nan"), device=dev)
+    nbytes = call("hpcs_gemm_tn_graph_workspace", B, C, N)
+    ws = torch.empty(nbytes // 4, device=dev)
+    call("hpcs_gemm_tn_graph", At, lda, feat, idx, B, C, N, k, M, got, ws, nbytes)
+    assert -(-M // 128) * -(-3 * L // 128) * B >= 32
+    assert torch.equal(got, ref)
+    # and against the definition in fp64
+    want = torch.einsum("mk,bkl->bml", W.double(), E.reshape(B, 2 * C, 3 * L).double())
+    assert (got.double() - want).abs().max() <= 1e-5 * want.abs().max()
+
+
+@pytest.mark.gpu
+def test_gemm_tn_graph_refuses_what_its_loader_cannot_do():
+    from hpcs_amd._lib import call, HpcsNativeError
+    dev = "cuda"
+    feat = torch.randn(1, 4, 3, 32, device=dev)
+    At = torch.zeros(8, 68, device=dev)
+    out = torch.empty(1, 65, 3 * 32 * 8, device=dev)
+    ws = torch.empty(1024, device=dev)
+    with pytest.raises(HpcsNativeError):                                   # k % 4 != 0
+        call("hpcs_gemm_tn_graph", At, 68, feat, torch.zeros(1, 32, 6, dtype=torch.int64, device=dev), 1, 4, 32, 6, 8, out, ws, 4096)
+    with pytest.raises(HpcsNativeError):                                   # more than one 64-row tile
+        call("hpcs_gemm_tn_graph", At, 68, feat, torch.zeros(1, 32, 8, dtype=torch.int64, device=dev), 1, 4, 32, 8, 65, out, ws, 4096)
