@@ -867,6 +867,117 @@ __global__ __launch_bounds__(1024) void split_reduce_kernel(const float* __restr
     }
 }
 
+// Weight gradient of the LARGE layers (VNStdFeature's vn1 / vn2: 682 x 341 and 340 x 341 over 98 k columns, 46 + 23 GFLOP):
+// 128 x 128 output tile, 64 x 64 per wave (four accumulators: every operand fetched from LDS feeds two MFMAs), 16-deep
+// steps, double-buffered LDS.  Both operands are reduction-contiguous in memory ("NT"), the MFMA wants them reduction-MAJOR:
+// the 16-byte global pieces are transposed on their way into LDS (four ds_write_b32, row pitch 132: the inherent two-way
+// conflict of 64 lanes on 32 banks), after which the inner loop is the forward GEMM's (conflict-free ds_read_b32, operand
+// mapping of tn_tile).  The 64 x 64 tile kernel below moves 16 flop per operand byte through L2 -> LDS and reached 60-70
+// TFLOP/s on these two shapes while starving the main stream's streaming kernels next to it; this one moves 32.
+// Split partials go to `part` (summed by split_reduce_kernel: two more launches for two GEMMs per step).
+constexpr int NB_BK = 16, NB_P = 132;
+#ifndef NB_REMAP
+#define NB_REMAP 1
+#endif
+__global__ __launch_bounds__(256, 4) void gemm_nt_big_kernel(
+    const float* __restrict__ G, int ldg, int64_t sGo, int64_t sGi, const float* __restrict__ X, int ldx, int64_t sXo,
+    int64_t sXi, int M, int Kx, int Nc, int n_inner, int n_batch, int chunk, int units_per_batch, int nsplit,
+    float* __restrict__ part, int tilesM, int tilesK, int vecG, int vecX) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * NB_BK * 2 * NB_P];
+    float (*As)[NB_BK][NB_P] = reinterpret_cast<float (*)[NB_BK][NB_P]>(lds);
+    float (*Bs)[NB_BK][NB_P] = reinterpret_cast<float (*)[NB_BK][NB_P]>(lds + 2 * NB_BK * NB_P);
+    static_assert(true, "");
+    const unsigned bid = NB_REMAP ? hpcs_xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int tile = bid % (tilesM * tilesK);
+    const int split = bid / (tilesM * tilesK);
+    const int m0 = (tile % tilesM) * 128, x0 = (tile / tilesM) * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 31, lk = lane >> 5;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // The reduction is ONE list of 16-column steps over all batches (steps_per_batch = ceil(Nc / 16)); split s owns the
+    // contiguous range [s T / nsplit, (s + 1) T / nsplit): equal work per workgroup whatever the batch count (the unit lists
+    // of the 64 x 64 kernel gave 56 splits of 64 units one or two units each).  `chunk` / `units_per_batch` are unused here.
+    (void)chunk; (void)units_per_batch;
+    const int spb = (Nc + NB_BK - 1) / NB_BK;
+    const int64_t T = (int64_t)n_batch * spb;
+    int64_t g = (int64_t)split * T / nsplit;
+    const int64_t g_end = (int64_t)(split + 1) * T / nsplit;
+    // 128 rows x 16 columns per operand and step = 512 16-byte pieces: two per thread (row = piece / 4)
+    float4 rg[2], rx[2];
+    auto gload = [&](int64_t gs) {
+        const int batch = (int)(gs / spb);
+        const int c0 = (int)(gs % spb) * NB_BK;
+        const int bo = batch / n_inner, bi = batch % n_inner;
+        const float* Gp = G + bo * sGo + bi * sGi;
+        const float* Xp = X + bo * sXo + bi * sXi;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = tid + i * 256, row = f >> 2, c4 = (f & 3) * 4;
+            rg[i] = ld4_guard(Gp + (int64_t)(m0 + row) * ldg, c0 + c4, Nc, m0 + row < M, vecG);
+            rx[i] = ld4_guard(Xp + (int64_t)(x0 + row) * ldx, c0 + c4, Nc, x0 + row < Kx, vecX);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = tid + i * 256, row = f >> 2, c4 = (f & 3) * 4;
+            As[buf][c4][row] = rg[i].x; As[buf][c4 + 1][row] = rg[i].y; As[buf][c4 + 2][row] = rg[i].z; As[buf][c4 + 3][row] = rg[i].w;
+            Bs[buf][c4][row] = rx[i].x; Bs[buf][c4 + 1][row] = rx[i].y; Bs[buf][c4 + 2][row] = rx[i].z; Bs[buf][c4 + 3][row] = rx[i].w;
+        }
+    };
+    // 32 x 32 blocks that lie entirely in the padding of an edge tile issue no MFMA (682 x 341 in 128 x 128 tiles: 242 of 288)
+    bool live[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) live[i][j] = (m0 + wm * 64 + i * 32 < M) && (x0 + wn * 64 + j * 32 < Kx);
+    if (g < g_end) {
+        gload(g);
+        lstore(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (; g < g_end; ++g) {
+        const bool have_next = g + 1 < g_end;
+        if (have_next) gload(g + 1);
+#pragma unroll
+        for (int kk = 0; kk < NB_BK / 2; ++kk) {
+            float a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = As[buf][kk * 2 + lk][wm * 64 + i * 32 + lr];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = Bs[buf][kk * 2 + lk][wn * 64 + j * 32 + lr];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    if (live[i][j]) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (have_next) lstore(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    float* P = part + (int64_t)split * M * Kx;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = x0 + wn * 64 + j * 32 + lr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (row < M && col < Kx) P[(int64_t)row * Kx + col] = acc[i][j][r];
+            }
+        }
+}
+
 constexpr int SR_SLICES = 32;   // first-level slices of the two-level split reduction
 inline bool sr_two_level(int nsplit, int64_t ne) { return nsplit >= 256 && ne <= 64 * 512; }
 
@@ -887,7 +998,9 @@ static long nt_wg_target() {
 NtPlan nt_plan(int M, int Kx, int Nc, int n_batch) {
     NtPlan p;
     const long WG = nt_wg_target();
-    p.tile = (M > 512 && Kx > 512) ? 128 : 64;     // measured: 128x128 tiles only pay for the 682x682 layer
+    // 128 x 128 tiles (gemm_nt_big_kernel) from 300 x 300 outputs up: VNStdFeature's vn1 / vn2 weight gradients
+    static const int big_min = [] { const char* e = getenv("HPCS_NT_BIG_MIN"); return e ? atoi(e) : 300; }();
+    p.tile = (M >= big_min && Kx >= big_min) ? 128 : 64;
     p.tilesM = hpcs_cdiv(M, p.tile);
     p.tilesK = hpcs_cdiv(Kx, p.tile);
     // one output tile (EdgeConv weight gradients: M, K <= 64 over ~2 M columns): MFMA (102 us) and HBM (147 us) phases of a
@@ -908,6 +1021,17 @@ NtPlan nt_plan(int M, int Kx, int Nc, int n_batch) {
             if (c < 64) c = 64;
             if (c < p.chunk) p.chunk = (int)c;
         }
+    }
+    if (p.tile == 128) {
+        // gemm_nt_big_kernel: one round of four workgroups per CU, the step list cut into equal ranges
+        p.chunk = Nc;
+        p.units_per_batch = 1;
+        const long T = (long)n_batch * hpcs_cdiv(Nc, 16);
+        long ns = 1024 / ((long)p.tilesM * p.tilesK);
+        if (ns < 1) ns = 1;
+        if (ns > T) ns = T;
+        p.nsplit = (int)ns;
+        return p;
     }
     p.units_per_batch = hpcs_cdiv(Nc, p.chunk);
     const long units = (long)n_batch * p.units_per_batch;
@@ -1140,9 +1264,9 @@ static int gemm_nt_impl(const float* G, int ldg, int64_t strideG_o, int64_t stri
                            strideX_o, strideX_i, M, Kx, Nc, n_inner, nb, p.chunk, p.units_per_batch, p.nsplit, (float*)ws, vecG,
                            vecX, fuse);
     else if (p.tile == 128)
-        hipLaunchKernelGGL((gemm_nt_kernel<128, 128, NT_BKC, 2, 2>), dim3((unsigned)blocks), dim3(256), 0, st, G, ldg,
-                           strideG_o, strideG_i, X, ldx, strideX_o, strideX_i, M, Kx, Nc, n_inner, nb, p.chunk,
-                           p.units_per_batch, p.nsplit, (float*)ws, p.tilesM, p.tilesK, vecG, vecX, fuse);
+        hipLaunchKernelGGL(gemm_nt_big_kernel, dim3((unsigned)blocks), dim3(256), 0, st, G, ldg, strideG_o, strideG_i, X, ldx,
+                           strideX_o, strideX_i, M, Kx, Nc, n_inner, nb, p.chunk, p.units_per_batch, p.nsplit, (float*)ws,
+                           p.tilesM, p.tilesK, vecG, vecX);
     else
         hipLaunchKernelGGL((gemm_nt_kernel<64, 64, NT_BKC, 2, 2>), dim3((unsigned)blocks), dim3(256), 0, st, G, ldg,
                            strideG_o, strideG_i, X, ldx, strideX_o, strideX_i, M, Kx, Nc, n_inner, nb, p.chunk,
