@@ -396,15 +396,18 @@ __device__ __forceinline__ void k2_vec(const float* __restrict__ E, int64_t b, i
 template <bool K2>
 __global__ __launch_bounds__(TPB) void vn_norm_stats_vec_kernel(const float* __restrict__ PD, int Ctot, int64_t L, int Cout,
                                                                double* __restrict__ sums, const float* __restrict__ w2, int ldw,
-                                                               BnFin fin) {
+                                                               BnFin fin, int items) {
     __shared__ double red[16];
     const int c = blockIdx.y, b = blockIdx.z;
     const float* base = PD + (((int64_t)b * Ctot + c) * 3) * L;
     const float w0 = K2 ? w2[(int64_t)c * ldw] : 0.f, w1 = K2 ? w2[(int64_t)c * ldw + 1] : 0.f;
     float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int it = 0; it < VEC_ITEMS; ++it) {
-        const int64_t l = ((int64_t)blockIdx.x * VEC_ITEMS + it) * (TPB * 4) + threadIdx.x * 4;
+    // `items` x 1024 positions per workgroup, chosen by the launcher: the two block reductions, the two fp64 atomics and the
+    // fold's ticket are a fixed ~3 us tail per workgroup -- at 2 x 1024 positions (24 KB of loads) it halved the streaming
+    // rate of the EdgeConv layers' pass (165 MB in 64-75 us = 2.2-2.6 TB/s where its siblings run at 5)
+#pragma unroll 2
+    for (int it = 0; it < items; ++it) {
+        const int64_t l = ((int64_t)blockIdx.x * items + it) * (TPB * 4) + threadIdx.x * 4;
         if (l < L) {
             float px[4], py[4], pz[4];
             if (K2) {
@@ -2201,15 +2204,24 @@ static int vn_norm_stats_impl(PdRef pd, int B, int Cout, double* sums, int zeroe
         if (const int zr = hpcs_zero_async(st, sums, sizeof(double) * 2 * Cout)) return zr;
     if (B == 0) return HPCS_OK;
     const bool vec_ok = pd.idx == nullptr && pd.L % 4 == 0 && (((uintptr_t)pd.base & 15u) == 0) && B <= 65535 && Cout <= 65535;
+    // positions per workgroup: as many 1024-blocks as still leave ~2500 workgroups for the chip (at least VEC_ITEMS, at most 8)
+    int items = VEC_ITEMS;
+    {
+        const int64_t blocks1k = hpcs_cdiv(pd.L, TPB * 4);
+        const int64_t rows = (int64_t)B * Cout;
+        while (items < 8 && hpcs_cdiv(blocks1k, items + 1) * rows >= 2500) ++items;
+        items = hpcs_cdiv(blocks1k, hpcs_cdiv(blocks1k, items));           // same workgroup count, evenly filled
+        if (items < 1) items = 1;
+    }
     if (vec_ok && pd.w2 == nullptr)
-        hipLaunchKernelGGL(vn_norm_stats_vec_kernel<false>, dim3(hpcs_cdiv(pd.L, TPB * 4 * VEC_ITEMS), Cout, B), dim3(TPB), 0, st,
-                           pd.base, pd.Ctot, pd.L, Cout, sums, (const float*)nullptr, 0, fin);
+        hipLaunchKernelGGL(vn_norm_stats_vec_kernel<false>, dim3(hpcs_cdiv(pd.L, TPB * 4 * items), Cout, B), dim3(TPB), 0, st,
+                           pd.base, pd.Ctot, pd.L, Cout, sums, (const float*)nullptr, 0, fin, items);
     else if (vec_ok && Cout == 21 && pd.Ctot == 42)
         hipLaunchKernelGGL(vn_norm_stats_k2all_kernel<21>, dim3(hpcs_cdiv(pd.L, TPB * 4), B), dim3(TPB), 0, st, pd.base, pd.w2,
                            pd.ldw, pd.L, sums, fin);
     else if (vec_ok)
-        hipLaunchKernelGGL(vn_norm_stats_vec_kernel<true>, dim3(hpcs_cdiv(pd.L, TPB * 4 * VEC_ITEMS), Cout, B), dim3(TPB), 0, st,
-                           pd.base, pd.Ctot, pd.L, Cout, sums, pd.w2, pd.ldw, fin);
+        hipLaunchKernelGGL(vn_norm_stats_vec_kernel<true>, dim3(hpcs_cdiv(pd.L, TPB * 4 * items), Cout, B), dim3(TPB), 0, st,
+                           pd.base, pd.Ctot, pd.L, Cout, sums, pd.w2, pd.ldw, fin, items);
     else
         hipLaunchKernelGGL(vn_norm_stats_kernel, dim3(hpcs_cdiv((int64_t)B * pd.L, TPB * ITEMS), Cout), dim3(TPB), 0, st, pd, B,
                            pd.Ctot, pd.L, Cout, sums, fin);
