@@ -1340,6 +1340,153 @@ __global__ void bn_act_bwd_apply_kernel(const float* __restrict__ Y, const float
     gY[off] = r;
 }
 
+// ---- 16-byte forms of the four Conv1d-head kernels (L % 4 == 0, aligned bases).  The scalar forms above pay two 64-bit
+// divisions per element and, in the reductions, a ~3 us block-sum + atomics tail per 2048 elements: 33 MB passes ran at
+// 1.3-1.9 TB/s (r03).  Here blockIdx.y = channel, blockIdx.z = cloud (elementwise) or a group of `bpw` clouds (reductions,
+// sized by the launcher so that ~2000 workgroups share the tensor), a thread owns four consecutive positions.
+__device__ __forceinline__ void bn_drop4(float (&m)[4], const float* __restrict__ mask, int64_t off, unsigned long long dseed,
+                                         unsigned dthr, float dinv) {
+    if (mask) {
+        const float4 q = *reinterpret_cast<const float4*>(mask + off);
+        m[0] = q.x; m[1] = q.y; m[2] = q.z; m[3] = q.w;
+    } else if (dthr) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) m[i] = hpcs_dropout_mult(dseed, off + i, dthr, dinv);
+    } else {
+        m[0] = m[1] = m[2] = m[3] = 1.f;
+    }
+}
+__global__ __launch_bounds__(TPB) void bn_stats_vec_kernel(const float* __restrict__ Y, int B, int C, int64_t L, int bpw,
+                                                          double* __restrict__ sums, BnFin fin) {
+    __shared__ double red[16];
+    const int c = blockIdx.y;
+    const int b0 = blockIdx.x * bpw, b1 = min(B, b0 + bpw);
+    float s1 = 0.f, s2 = 0.f;
+    for (int b = b0; b < b1; ++b) {
+        const float* row = Y + ((int64_t)b * C + c) * L;
+        for (int64_t l = (int64_t)threadIdx.x * 4; l < L; l += TPB * 4) {
+            const float4 v = *reinterpret_cast<const float4*>(row + l);
+            s1 += (v.x + v.y) + (v.z + v.w);
+            s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        }
+    }
+    const double r1 = hpcs_block_sum<double>((double)s1, red);
+    const double r2 = hpcs_block_sum<double>((double)s2, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(sums + c, r1);
+        atomicAdd(sums + C + c, r2);
+        bn_finalize_tail_channel(fin, sums, C, c, gridDim.x);
+    }
+}
+__global__ __launch_bounds__(TPB) void bn_act_fwd_vec_kernel(
+    const float* __restrict__ Y, const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ mask, int C, int64_t L, float slope, float* __restrict__ out,
+    unsigned long long dseed, const unsigned long long* __restrict__ dseed_dev, unsigned dthr, float dinv) {
+    if (dseed_dev) dseed = *dseed_dev;
+    const int c = blockIdx.y, b = blockIdx.z;
+    const int64_t l = ((int64_t)blockIdx.x * TPB + threadIdx.x) * 4;
+    if (l >= L) return;
+    const int64_t off = ((int64_t)b * C + c) * L + l;
+    const float mu = mean[c], sc = rstd[c] * gamma[c], be = beta[c], rs = rstd[c], ga = gamma[c];
+    (void)sc;
+    const float4 y = *reinterpret_cast<const float4*>(Y + off);
+    float m[4];
+    bn_drop4(m, mask, off, dseed, dthr, dinv);
+    const float yv[4] = {y.x, y.y, y.z, y.w};
+    float o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float z = (yv[i] - mu) * rs * ga + be;           // the scalar kernel's expression, same rounding
+        o[i] = (z > 0.f ? z : z * slope);
+        if (mask || dthr) o[i] *= m[i];
+    }
+    *reinterpret_cast<float4*>(out + off) = make_float4(o[0], o[1], o[2], o[3]);
+}
+__global__ __launch_bounds__(TPB) void bn_act_bwd_reduce_vec_kernel(
+    const float* __restrict__ Y, const float* __restrict__ gout, const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mask, int B, int C, int64_t L,
+    int bpw, float slope, double* __restrict__ red_out, unsigned long long dseed, const unsigned long long* __restrict__ dseed_dev,
+    unsigned dthr, float dinv) {
+    __shared__ double red[16];
+    if (dseed_dev) dseed = *dseed_dev;
+    const int c = blockIdx.y;
+    const int b0 = blockIdx.x * bpw, b1 = min(B, b0 + bpw);
+    const float mu = mean[c], rs = rstd[c], ga = gamma[c], be = beta[c];
+    float s1 = 0.f, s2 = 0.f;
+    for (int b = b0; b < b1; ++b) {
+        const int64_t rowoff = ((int64_t)b * C + c) * L;
+        for (int64_t l = (int64_t)threadIdx.x * 4; l < L; l += TPB * 4) {
+            const int64_t off = rowoff + l;
+            const float4 y = *reinterpret_cast<const float4*>(Y + off);
+            const float4 gq = *reinterpret_cast<const float4*>(gout + off);
+            float m[4];
+            bn_drop4(m, mask, off, dseed, dthr, dinv);
+            const float yv[4] = {y.x, y.y, y.z, y.w}, gv[4] = {gq.x, gq.y, gq.z, gq.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float xh = (yv[i] - mu) * rs;
+                const float z = xh * ga + be;
+                float g = gv[i];
+                if (mask || dthr) g *= m[i];
+                g *= z > 0.f ? 1.f : slope;
+                s1 += g;
+                s2 += g * xh;
+            }
+        }
+    }
+    const double r1 = hpcs_block_sum<double>((double)s1, red);
+    const double r2 = hpcs_block_sum<double>((double)s2, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(red_out + c, r1);
+        atomicAdd(red_out + C + c, r2);
+    }
+}
+__global__ __launch_bounds__(TPB) void bn_act_bwd_apply_vec_kernel(
+    const float* __restrict__ Y, const float* __restrict__ gout, const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mask, const double* __restrict__ red,
+    int training, int B, int C, int64_t L, float slope, float* __restrict__ gY, unsigned long long dseed,
+    const unsigned long long* __restrict__ dseed_dev, unsigned dthr, float dinv, float* __restrict__ ggamma,
+    float* __restrict__ gbeta) {
+    if (dseed_dev) dseed = *dseed_dev;
+    const int c = blockIdx.y, b = blockIdx.z;
+    if (ggamma && blockIdx.x == 0 && b == 0 && threadIdx.x == 0) {
+        ggamma[c] += (float)red[C + c];
+        gbeta[c] += (float)red[c];
+    }
+    const int64_t l = ((int64_t)blockIdx.x * TPB + threadIdx.x) * 4;
+    if (l >= L) return;
+    const double count = (double)B * (double)L;
+    const int64_t off = ((int64_t)b * C + c) * L + l;
+    const float rs = rstd[c], ga = gamma[c], mu = mean[c], be = beta[c];
+    const float m1 = training ? (float)(red[c] / count) : 0.f, m2 = training ? (float)(red[C + c] / count) : 0.f;
+    const float4 y = *reinterpret_cast<const float4*>(Y + off);
+    const float4 gq = *reinterpret_cast<const float4*>(gout + off);
+    float m[4];
+    bn_drop4(m, mask, off, dseed, dthr, dinv);
+    const float yv[4] = {y.x, y.y, y.z, y.w}, gv[4] = {gq.x, gq.y, gq.z, gq.w};
+    float r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float xh = (yv[i] - mu) * rs;
+        const float z = xh * ga + be;
+        float g = gv[i];
+        if (mask || dthr) g *= m[i];
+        g *= z > 0.f ? 1.f : slope;
+        r[i] = training ? rs * ga * (g - m1 - xh * m2) : rs * ga * g;
+    }
+    *reinterpret_cast<float4*>(gY + off) = make_float4(r[0], r[1], r[2], r[3]);
+}
+// clouds per workgroup of the two reductions: ~2000 workgroups over the C x B rows
+static inline int bn_bpw(int B, int C) {
+    int bpw = (int)(((int64_t)B * C + 1999) / 2000);
+    if (bpw < 1) bpw = 1;
+    if (bpw > B) bpw = B;
+    return bpw;
+}
+static inline bool bn_vec_ok(int B, int64_t L, const void* a, const void* b, const void* c, const void* d) {
+    return L % 4 == 0 && B <= 65535 && ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d) & 15u) == 0);
+}
+
 // the multiplier tensor the bn_act kernels apply implicitly for (seed, p): element i = 1/(1-p) or 0 (tests, debugging)
 __global__ void dropout_mask_kernel(unsigned long long seed, unsigned thr, float inv, int64_t n, float* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2630,7 +2777,12 @@ extern "C" int hpcs_bn_stats(const float* Y, int B, int C, int64_t L, double* su
     if (!sums_zeroed)
         if (const int zr = hpcs_zero_async(ST, sums, sizeof(double) * 2 * C)) return zr;
     if (B == 0) return HPCS_OK;
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(hpcs_cdiv((int64_t)B * L, TPB * ITEMS), C), dim3(TPB), 0, ST, Y, B, C, L, sums, NO_FIN);
+    if (bn_vec_ok(B, L, Y, nullptr, nullptr, nullptr)) {
+        const int bpw = bn_bpw(B, C);
+        hipLaunchKernelGGL(bn_stats_vec_kernel, dim3(hpcs_cdiv(B, bpw), C), dim3(TPB), 0, ST, Y, B, C, L, bpw, sums, NO_FIN);
+    } else {
+        hipLaunchKernelGGL(bn_stats_kernel, dim3(hpcs_cdiv((int64_t)B * L, TPB * ITEMS), C), dim3(TPB), 0, ST, Y, B, C, L, sums, NO_FIN);
+    }
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;
 }
@@ -2645,6 +2797,11 @@ extern "C" int hpcs_bn_act_fwd(const float* Y, const float* mean, const float* r
     if (!Y || !mean || !rstd || !gamma || !beta || !out) return HPCS_ERR_NULL;
     if (bad_dims(B, C, L) || C > 65535) return HPCS_ERR_SHAPE;
     if (B == 0) return HPCS_OK;
+    if (bn_vec_ok(B, L, Y, out, mask, nullptr))
+        hipLaunchKernelGGL(bn_act_fwd_vec_kernel, dim3(hpcs_cdiv(L, TPB * 4), C, B), dim3(TPB), 0, ST, Y, mean, rstd, gamma, beta,
+                           mask, C, L, slope, out, (unsigned long long)drop_seed, (const unsigned long long*)drop_seed_dev,
+                           drop_thresh(drop_p), drop_inv(drop_p));
+    else
     hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(hpcs_cdiv((int64_t)B * L, TPB), C), dim3(TPB), 0, ST, Y, mean, rstd, gamma,
                        beta, mask, B, C, L, slope, out, (unsigned long long)drop_seed,
                        (const unsigned long long*)drop_seed_dev, drop_thresh(drop_p), drop_inv(drop_p));
@@ -2662,6 +2819,12 @@ extern "C" int hpcs_bn_act_bwd_reduce(const float* Y, const float* gout, const f
     if (!red_zeroed)
         if (const int zr = hpcs_zero_async(ST, red, sizeof(double) * 2 * C)) return zr;
     if (B == 0) return HPCS_OK;
+    if (bn_vec_ok(B, L, Y, gout, mask, nullptr)) {
+        const int bpw = bn_bpw(B, C);
+        hipLaunchKernelGGL(bn_act_bwd_reduce_vec_kernel, dim3(hpcs_cdiv(B, bpw), C), dim3(TPB), 0, ST, Y, gout, mean, rstd, gamma,
+                           beta, mask, B, C, L, bpw, slope, red, (unsigned long long)drop_seed,
+                           (const unsigned long long*)drop_seed_dev, drop_thresh(drop_p), drop_inv(drop_p));
+    } else
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(hpcs_cdiv((int64_t)B * L, TPB * ITEMS), C), dim3(TPB), 0, ST, Y, gout,
                        mean, rstd, gamma, beta, mask, B, C, L, slope, red, (unsigned long long)drop_seed,
                        (const unsigned long long*)drop_seed_dev, drop_thresh(drop_p), drop_inv(drop_p));
@@ -2678,6 +2841,11 @@ extern "C" int hpcs_bn_act_bwd_apply(const float* Y, const float* gout, const fl
     if ((ggamma == nullptr) != (gbeta == nullptr) || (ggamma && !red)) return HPCS_ERR_NULL;
     if (bad_dims(B, C, L) || C > 65535) return HPCS_ERR_SHAPE;
     if (B == 0) return HPCS_OK;
+    if (bn_vec_ok(B, L, Y, gout, mask, gY))
+        hipLaunchKernelGGL(bn_act_bwd_apply_vec_kernel, dim3(hpcs_cdiv(L, TPB * 4), C, B), dim3(TPB), 0, ST, Y, gout, mean, rstd,
+                           gamma, beta, mask, red, training, B, C, L, slope, gY, (unsigned long long)drop_seed,
+                           (const unsigned long long*)drop_seed_dev, drop_thresh(drop_p), drop_inv(drop_p), ggamma, gbeta);
+    else
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(hpcs_cdiv((int64_t)B * L, TPB), C), dim3(TPB), 0, ST, Y, gout, mean,
                        rstd, gamma, beta, mask, red, training, B, C, L, slope, gY, (unsigned long long)drop_seed,
                        (const unsigned long long*)drop_seed_dev, drop_thresh(drop_p), drop_inv(drop_p), ggamma, gbeta);
@@ -2861,6 +3029,11 @@ extern "C" int hpcs_bn_stats_finalize(const float* Y, int B, int C, int64_t L, d
     int rc = fin_args_ok(sums, counter, mean, rstd, (int64_t)B * L);
     if (rc) return rc;
     if (bad_dims(B, C, L) || C > 65535 || B == 0) return HPCS_ERR_SHAPE;
+    if (bn_vec_ok(B, L, Y, nullptr, nullptr, nullptr)) {
+        const int bpw = bn_bpw(B, C);
+        hipLaunchKernelGGL(bn_stats_vec_kernel, dim3(hpcs_cdiv(B, bpw), C), dim3(TPB), 0, ST, Y, B, C, L, bpw, sums,
+                           bn_fin(counter, (int64_t)B * L, eps, momentum, running_mean, running_var, mean, rstd));
+    } else
     hipLaunchKernelGGL(bn_stats_kernel, dim3(hpcs_cdiv((int64_t)B * L, TPB * ITEMS), C), dim3(TPB), 0, ST, Y, B, C, L, sums,
                        bn_fin(counter, (int64_t)B * L, eps, momentum, running_mean, running_var, mean, rstd));
     HPCS_CHECK_LAUNCH();
