@@ -37,6 +37,13 @@ __device__ __forceinline__ int grp_bcast(int x) {
 }
 template <int C>
 __device__ __forceinline__ float grp_bcast(float x) { return __int_as_float(grp_bcast<C>(__float_as_int(x))); }
+// the other quad's value of the same position: lane s <- lane s ^ 4 (row_shr:4 into the upper quads, row_shl:4 into the lower)
+__device__ __forceinline__ float grp_other_half(float x) {
+    const int v = __float_as_int(x);
+    int t = __builtin_amdgcn_update_dpp(v, v, 0x114, 0xF, 0xA, false);        // upper quads <- lane - 4
+    t = __builtin_amdgcn_update_dpp(t, v, 0x104, 0xF, 0x5, false);            // lower quads <- lane + 4
+    return __int_as_float(t);
+}
 // lane s <- lane s+1 (the group's last lane receives its neighbour group's first value or keeps its own: unused)
 __device__ __forceinline__ int grp_shift_down(int x) { return __builtin_amdgcn_update_dpp(x, x, 0x101, 0xF, 0xF, false); }
 // sum over the 8 lanes of a group, result in all of them: xor-1, xor-2 inside quads, then the mirrored other quad
@@ -1110,7 +1117,16 @@ __global__ __launch_bounds__(SB_THREADS) void hyphc_sampled4_kernel(
         bool live = lv_own;
         if (kind >= 0) live = live && keep_rule(0.5f * (1.f + D1) - 0.5f * (1.f + D2), margin, kind);
         if (live && owner) ++kept;
-        const LcaF L1 = lca_of_dot(sc, D1), L2 = lca_of_dot(sc, D2), L3 = lca_of_dot(sc, D3);
+        // Lanes s and s + 4 hold the same triplet: the lower quad evaluates the (a, p) distance, the upper quad the (p, n)
+        // distance, then they swap -- two LCA evaluations per lane instead of three.
+        LcaF L1, L3;
+        {
+            const LcaF Lx = lca_of_dot(sc, owner ? D1 : D3);
+            const float od = grp_other_half(Lx.d), ow = grp_other_half(Lx.dd_dw), os = grp_other_half(Lx.dd_ds);
+            L1.d = owner ? Lx.d : od; L1.dd_dw = owner ? Lx.dd_dw : ow; L1.dd_ds = owner ? Lx.dd_ds : os;
+            L3.d = owner ? od : Lx.d; L3.dd_dw = owner ? ow : Lx.dd_dw; L3.dd_ds = owner ? os : Lx.dd_ds;
+        }
+        const LcaF L2 = lca_of_dot(sc, D2);
         const float q0 = L1.d * inv_t, q1 = L2.d * inv_t, q2 = L3.d * inv_t;
         const float mx = fmaxf(q0, fmaxf(q1, q2));
         const float e0 = __expf(q0 - mx), e1 = __expf(q1 - mx), e2 = __expf(q2 - mx);

@@ -330,7 +330,13 @@ def _bn_grads(ctx_params, red, C, needs_gamma, needs_beta):
     return ggamma, gbeta
 
 
-def _on_side_stream(work, keep_alive):
+SIDE_INLINE_BIG = int(__import__("os").environ.get("HPCS_SIDE_INLINE_BIG", "0"))    # experiment: 0 = everything on the side stream
+
+
+def _on_side_stream(work, keep_alive, size=0):
+    if SIDE_INLINE_BIG and size >= SIDE_INLINE_BIG:
+        work()                                   # in line, on the main stream
+        return
     main = torch.cuda.current_stream()
     side = _SideWGrad.stream
     side.wait_stream(main)
@@ -694,7 +700,7 @@ class VNLayerFn(torch.autograd.Function):
             both = None if Cc else _stacked_sink(sink_f, sink_d, Cout, Cd, Cin)
             if both is not None and (sink_d is not None or not Cd):
                 # feature and direction weights lie back to back in the bucket: the stacked GEMM adds straight into them
-                _on_side_stream(lambda: gemm_GXt(GPD, x, B, Ctot, Cin, 3 * L, out=both), (GPD, x))
+                _on_side_stream(lambda: gemm_GXt(GPD, x, B, Ctot, Cin, 3 * L, out=both), (GPD, x), size=Ctot * Cin)
             elif (sink_f is not None or not ctx.needs_input_grad[1]) and \
                     (sink_d is not None or not (Cd and ctx.needs_input_grad[2])):
                 def work():
