@@ -138,6 +138,9 @@ __device__ __forceinline__ void tn_tile(const float* __restrict__ At, int lda, c
             live[i][j] = (m0 + wm * (BM / WM) + i * 32 < M) && (n0 + wn * (BN / WN) + j * 32 < Nc);
             all_live = all_live && live[i][j];
         }
+    // (Measured and NOT kept, r03: requesting the operands of k-pair kk + 1 before the MFMAs of pair kk issue -- two register
+    // sets and scheduling barriers; the compiler's own order is read, wait, four MFMAs per pair -- vn1 forward 526 us against
+    // 490-510, step +0.1 ms: with four waves per SIMD the other waves already fill the LDS round trips.)
     auto mma = [&](int buf, auto full) {
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
