@@ -990,7 +990,9 @@ struct NtPlan { int tile, tilesM, tilesK, chunk, units_per_batch, nsplit; };
 static long nt_wg_target() {
     static long v = [] {
         const char* e = getenv("HPCS_NT_WG_TARGET");
-        long t = e ? atol(e) : 2048;
+        // 768 = three workgroups per CU: 2048 (eight) measured 1.3 % slower in the step, 10.25-10.29 vs 10.10-10.15 ms -- the
+        // weight gradients run next to the main stream's kernels and fewer, longer workgroups leave those more of the chip
+        long t = e ? atol(e) : 768;
         return t < 64 ? 64 : t;
     }();
     return v;
