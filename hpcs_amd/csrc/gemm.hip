@@ -1028,11 +1028,13 @@ NtPlan nt_plan(int M, int Kx, int Nc, int n_batch) {
         }
     }
     if (p.tile == 128) {
-        // gemm_nt_big_kernel: one round of four workgroups per CU, the step list cut into equal ranges
+        // gemm_nt_big_kernel: one round of workgroups, the step list cut into equal ranges
         p.chunk = Nc;
         p.units_per_batch = 1;
         const long T = (long)n_batch * hpcs_cdiv(Nc, 16);
-        long ns = 1024 / ((long)p.tilesM * p.tilesK);
+        // two workgroups per CU (512): 10.01-10.06 ms per step against 10.08-10.13 with four (1024); 256: 10.06
+        static const long big_wg = [] { const char* e = getenv("HPCS_NT_BIG_WG"); return e ? atol(e) : 512L; }();
+        long ns = big_wg / ((long)p.tilesM * p.tilesK);
         if (ns < 1) ns = 1;
         if (ns > T) ns = T;
         p.nsplit = (int)ns;
