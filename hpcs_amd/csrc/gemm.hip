@@ -569,8 +569,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(
     // are fetched with ds_read_b128 (four consecutive columns = two k-steps per lane); at a 144-byte pitch eight
     // consecutive rows cover the eight 16-byte bank groups, so both are conflict-free.  (A BKC + 1 pitch with scalar
     // LDS traffic made the EdgeConv shapes LDS-issue bound: 238 -> 178 us.)
-    // The 128x128 instantiation keeps the BKC + 1 pitch with scalar LDS traffic (odd pitch: the 32 rows of an operand
-    // fetch hit 32 banks): with 64 accumulator registers the vector form spills (measured 1.43 -> 2.29 ms).
+    // (BM = 128 is no longer instantiated: outputs from 300 x 300 up take gemm_nt_big_kernel.  Its branch here -- BKC + 1
+    // pitch, scalar LDS traffic, single-buffered -- measured 906 / 427 us on the 682 x 341 / 340 x 341 gradients.)
     constexpr bool V4 = BM == 64;
     constexpr int LD = V4 ? BKC + 4 : BKC + 1;
     constexpr int G_LD = BM * BKC / 4 / NT, X_LD = BN * BKC / 4 / NT;
@@ -879,9 +879,6 @@ __global__ __launch_bounds__(1024) void split_reduce_kernel(const float* __restr
 // TFLOP/s on these two shapes while starving the main stream's streaming kernels next to it; this one moves 32.
 // Split partials go to `part` (summed by split_reduce_kernel: two more launches for two GEMMs per step).
 constexpr int NB_BK = 16, NB_P = 132;
-#ifndef NB_REMAP
-#define NB_REMAP 1
-#endif
 __global__ __launch_bounds__(256, 4) void gemm_nt_big_kernel(
     const float* __restrict__ G, int ldg, int64_t sGo, int64_t sGi, const float* __restrict__ X, int ldx, int64_t sXo,
     int64_t sXi, int M, int Kx, int Nc, int n_inner, int n_batch, int chunk, int units_per_batch, int nsplit,
@@ -889,8 +886,8 @@ __global__ __launch_bounds__(256, 4) void gemm_nt_big_kernel(
     __shared__ __attribute__((aligned(16))) float lds[2 * NB_BK * 2 * NB_P];
     float (*As)[NB_BK][NB_P] = reinterpret_cast<float (*)[NB_BK][NB_P]>(lds);
     float (*Bs)[NB_BK][NB_P] = reinterpret_cast<float (*)[NB_BK][NB_P]>(lds + 2 * NB_BK * NB_P);
-    static_assert(true, "");
-    const unsigned bid = NB_REMAP ? hpcs_xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    // XCD-aware order: the tiles of one split (same column range of G and X) share an L2 (541 vs 550 us, 282 vs 292 us)
+    const unsigned bid = hpcs_xcd_remap(blockIdx.x, gridDim.x);
     const int tile = bid % (tilesM * tilesK);
     const int split = bid / (tilesM * tilesK);
     const int m0 = (tile % tilesM) * 128, x0 = (tile / tilesM) * 128;
@@ -1256,7 +1253,7 @@ static int gemm_nt_impl(const float* G, int ldg, int64_t strideG_o, int64_t stri
     const bool edge = p.tilesM * p.tilesK == 1 && M <= NE_T && Kx <= NE_T;
     NtFuse fuse{nullptr, stage, dW, lddw, accumulate, slice_len, slices, 0u, 0u};
     if (tickets && n_tickets < (size_t)p.tilesM * p.tilesK * (slices + 1)) return HPCS_ERR_WORKSPACE;
-    if (tickets && p.tile != 128) {           // (the 128 x 128 tile of the 682 x 682 layer does not fit the staging LDS: two launches)
+    if (tickets && p.tile != 128) {           // (gemm_nt_big_kernel writes plain partials: split_reduce launches follow)
         const size_t te = edge ? (size_t)NE_T * NE_T : (size_t)p.tile * p.tile;
         const size_t pb = (size_t)p.nsplit * p.tilesM * p.tilesK * te * sizeof(float);
         const size_t sb = (size_t)slices * p.tilesM * p.tilesK * te * sizeof(float);
