@@ -878,12 +878,17 @@ __global__ __launch_bounds__(1024) void split_reduce_kernel(const float* __restr
 // mapping of tn_tile).  The 64 x 64 tile kernel below moves 16 flop per operand byte through L2 -> LDS and reached 60-70
 // TFLOP/s on these two shapes while starving the main stream's streaming kernels next to it; this one moves 32.
 // Split partials go to `part` (summed by split_reduce_kernel: two more launches for two GEMMs per step).
-constexpr int NB_BK = 16, NB_P = 132;
-__global__ __launch_bounds__(256, 4) void gemm_nt_big_kernel(
+#ifndef HPCS_NB_BK
+#define HPCS_NB_BK 16      // 32-deep steps (66 KB of LDS, two workgroups per CU) measured 593 vs 614 us on vn1 and the same step time
+#endif
+constexpr int NB_BK = HPCS_NB_BK, NB_P = 132;
+constexpr int NB_PIECES = NB_BK / 4;          // 16-byte pieces per operand row and step
+constexpr int NB_LD = 128 * NB_PIECES / 256;   // pieces per thread and operand
+__global__ __launch_bounds__(256, NB_BK == 16 ? 4 : 2) void gemm_nt_big_kernel(
     const float* __restrict__ G, int ldg, int64_t sGo, int64_t sGi, const float* __restrict__ X, int ldx, int64_t sXo,
     int64_t sXi, int M, int Kx, int Nc, int n_inner, int n_batch, int chunk, int units_per_batch, int nsplit,
     float* __restrict__ part, int tilesM, int tilesK, int vecG, int vecX) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * NB_BK * 2 * NB_P];
+    extern __shared__ __attribute__((aligned(16))) float lds[];        // 2 * NB_BK * 2 * NB_P floats (dynamic: 66 KB at 32-deep steps)
     float (*As)[NB_BK][NB_P] = reinterpret_cast<float (*)[NB_BK][NB_P]>(lds);
     float (*Bs)[NB_BK][NB_P] = reinterpret_cast<float (*)[NB_BK][NB_P]>(lds + 2 * NB_BK * NB_P);
     // XCD-aware order: the tiles of one split (same column range of G and X) share an L2 (541 vs 550 us, 282 vs 292 us)
@@ -910,7 +915,7 @@ __global__ __launch_bounds__(256, 4) void gemm_nt_big_kernel(
     int64_t g = (int64_t)split * T / nsplit;
     const int64_t g_end = (int64_t)(split + 1) * T / nsplit;
     // 128 rows x 16 columns per operand and step = 512 16-byte pieces: two per thread (row = piece / 4)
-    float4 rg[2], rx[2];
+    float4 rg[NB_LD], rx[NB_LD];
     auto gload = [&](int64_t gs) {
         const int batch = (int)(gs / spb);
         const int c0 = (int)(gs % spb) * NB_BK;
@@ -918,16 +923,16 @@ __global__ __launch_bounds__(256, 4) void gemm_nt_big_kernel(
         const float* Gp = G + bo * sGo + bi * sGi;
         const float* Xp = X + bo * sXo + bi * sXi;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int f = tid + i * 256, row = f >> 2, c4 = (f & 3) * 4;
+        for (int i = 0; i < NB_LD; ++i) {
+            const int f = tid + i * 256, row = f / NB_PIECES, c4 = (f % NB_PIECES) * 4;
             rg[i] = ld4_guard(Gp + (int64_t)(m0 + row) * ldg, c0 + c4, Nc, m0 + row < M, vecG);
             rx[i] = ld4_guard(Xp + (int64_t)(x0 + row) * ldx, c0 + c4, Nc, x0 + row < Kx, vecX);
         }
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int f = tid + i * 256, row = f >> 2, c4 = (f & 3) * 4;
+        for (int i = 0; i < NB_LD; ++i) {
+            const int f = tid + i * 256, row = f / NB_PIECES, c4 = (f % NB_PIECES) * 4;
             As[buf][c4][row] = rg[i].x; As[buf][c4 + 1][row] = rg[i].y; As[buf][c4 + 2][row] = rg[i].z; As[buf][c4 + 3][row] = rg[i].w;
             Bs[buf][c4][row] = rx[i].x; Bs[buf][c4 + 1][row] = rx[i].y; Bs[buf][c4 + 2][row] = rx[i].z; Bs[buf][c4 + 3][row] = rx[i].w;
         }
@@ -976,6 +981,15 @@ __global__ __launch_bounds__(256, 4) void gemm_nt_big_kernel(
                 if (row < M && col < Kx) P[(int64_t)row * Kx + col] = acc[i][j][r];
             }
         }
+}
+
+static size_t nb_lds_bytes() {
+    static const size_t bytes = [] {
+        const size_t b = (size_t)2 * NB_BK * 2 * NB_P * sizeof(float);
+        (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
+        return b;
+    }();
+    return bytes;
 }
 
 constexpr int SR_SLICES = 32;   // first-level slices of the two-level split reduction
@@ -1028,7 +1042,7 @@ NtPlan nt_plan(int M, int Kx, int Nc, int n_batch) {
         // gemm_nt_big_kernel: one round of workgroups, the step list cut into equal ranges
         p.chunk = Nc;
         p.units_per_batch = 1;
-        const long T = (long)n_batch * hpcs_cdiv(Nc, 16);
+        const long T = (long)n_batch * hpcs_cdiv(Nc, NB_BK);
         // two workgroups per CU (512): 10.01-10.06 ms per step against 10.08-10.13 with four (1024); 256: 10.06
         static const long big_wg = [] { const char* e = getenv("HPCS_NT_BIG_WG"); return e ? atol(e) : 512L; }();
         long ns = big_wg / ((long)p.tilesM * p.tilesK);
@@ -1268,7 +1282,7 @@ static int gemm_nt_impl(const float* G, int ldg, int64_t strideG_o, int64_t stri
                            strideX_o, strideX_i, M, Kx, Nc, n_inner, nb, p.chunk, p.units_per_batch, p.nsplit, (float*)ws, vecG,
                            vecX, fuse);
     else if (p.tile == 128)
-        hipLaunchKernelGGL(gemm_nt_big_kernel, dim3((unsigned)blocks), dim3(256), 0, st, G, ldg, strideG_o, strideG_i, X, ldx,
+        hipLaunchKernelGGL(gemm_nt_big_kernel, dim3((unsigned)blocks), dim3(256), nb_lds_bytes(), st, G, ldg, strideG_o, strideG_i, X, ldx,
                            strideX_o, strideX_i, M, Kx, Nc, n_inner, nb, p.chunk, p.units_per_batch, p.nsplit, (float*)ws,
                            p.tilesM, p.tilesK, vecG, vecX);
     else
