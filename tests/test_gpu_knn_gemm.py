@@ -168,7 +168,11 @@ def test_gemm_tn_inner_batch():
 
 
 @pytest.mark.parametrize("M,Kx,Nc,nb", [(42, 42, 5000, 3), (341, 63, 3 * 256, 2), (682, 682, 3 * 64, 2), (256, 1, 1, 6),
-                                        (3, 170, 96, 4)])
+                                        (3, 170, 96, 4),
+                                        # gemm_nt_big_kernel (outputs from 300 x 300 up): VNStdFeature's two shapes with ragged tile
+                                        # edges (682 = 5 x 128 + 42, 341 = 2 x 128 + 85), a column count that is not a multiple
+                                        # of the 16-deep step, odd (unaligned) rows, fewer steps than splits
+                                        (682, 341, 3072, 3), (340, 341, 1000, 3), (301, 303, 77, 2), (300, 300, 8, 1)])
 def test_gemm_nt(M, Kx, Nc, nb):
     G = det_normalish((nb, M, Nc), 600 + M)
     X = det_normalish((nb, Kx, Nc), 700 + Kx)
@@ -181,7 +185,7 @@ def test_gemm_nt(M, Kx, Nc, nb):
 
 
 @pytest.mark.parametrize("M,Kx,Nc,nb", [(42, 42, 5000, 3), (42, 21, 61440, 8), (341, 63, 3 * 256, 2), (682, 682, 3 * 64, 2),
-                                        (256, 1, 1, 6), (3, 170, 96, 4), (64, 256, 1024, 32)])
+                                        (256, 1, 1, 6), (3, 170, 96, 4), (64, 256, 1024, 32), (340, 341, 1536, 2)])
 def test_gemm_nt_fused_reduction_equals_the_two_launch_form(M, Kx, Nc, nb):
     """hpcs_gemm_nt_fused: the split partials are summed by the last-arriving workgroup inside the launch (per slice of
     splits, then per tile; write-through partials, agent-scope tickets).  Checked against fp64, against the separate
