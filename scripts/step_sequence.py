@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""One training step's kernel launches in dispatch order from a rocprofv3 --kernel-trace CSV: start offset (us, from the start of
+the once-per-step sampled HypHC kernel), duration, queue, grid / workgroup x-size, LDS and VGPR use.  The step printed is the
+third from last.   usage: python3 scripts/step_sequence.py <kernel_trace.csv>"""
 import csv, sys
 rows = []
 for r in csv.DictReader(open(sys.argv[1])):
