@@ -59,3 +59,10 @@ extern "C" int hpcs_debug_watch(const void* watched, const void* shadow, int nby
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;
 }
+
+// Zero-fill of up to four buffers as ONE launch (csrc/common.h hpcs_zero_async): the step driver clears its flat gradient
+// bucket and its fp64 accumulator arena with it.  Sizes in bytes, multiples of 4; NULL pointers are skipped.
+extern "C" int hpcs_zero_buffers(void* p0, size_t n0, void* p1, size_t n1, void* p2, size_t n2, void* p3, size_t n3,
+                                 hpcs_stream_t stream) {
+    return hpcs_zero_async((hipStream_t)stream, p0, n0, p1, n1, p2, n2, p3, n3);
+}

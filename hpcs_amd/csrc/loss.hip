@@ -1811,7 +1811,7 @@ extern "C" int hpcs_cosface_bwd(const float* xn, const float* wn, const int64_t*
     if (!xn || !wn || !labels || !logits || !lse_rows || !gloss || !gxn || !gwn) return HPCS_ERR_NULL;
     if (M < 0 || E <= 0 || C <= 0 || (size_t)C * E * 4 > 64 * 1024) return HPCS_ERR_SHAPE;
     if (n_levels < 1 || n_levels > MAX_LEVELS || (n_levels > 1 && !branch_id)) return HPCS_ERR_SHAPE;
-    if (const int zr = hpcs_zero_async(ST, gwn, sizeof(float) * C * E)) return zr;
+    if (const int zr = hpcs_zero_async(ST, gwn, sizeof(float) * C * E, gxn, sizeof(float) * (size_t)M * E)) return zr;
     if (M == 0) return HPCS_OK;
     const size_t tile_lds = ((size_t)C * E + CF_ROWS * (E + 1) + CF_ROWS * (C + 1)) * 4;
     if (tile_lds <= 64 * 1024 && C * E <= 256 * CF_MAXOUT) {
@@ -1950,7 +1950,9 @@ extern "C" int hpcs_hyphc_sampled(const float* xn, const int64_t* labels, const 
     if ((a_dbg || p_dbg || n_dbg) && !(a_dbg && p_dbg && n_dbg)) return HPCS_ERR_NULL;
     if (C <= 0 || M <= 0 || T < 0 || !(temperature > 0.f) || kind > 3) return HPCS_ERR_SHAPE;
     if (E != 16 && E != 32 && E != 64) return HPCS_ERR_UNSUPPORTED;
-    if (const int zr = hpcs_zero_async(ST, loss_sum, sizeof(double), kept, sizeof(int64_t), gscale, sizeof(double))) return zr;
+    if (const int zr = hpcs_zero_async(ST, loss_sum, sizeof(double), kept, sizeof(int64_t), gscale, sizeof(double), gxn,
+                                       gxn ? sizeof(float) * (size_t)M * E : 0))
+        return zr;
     if (T == 0) return HPCS_OK;
     // Workgroups are resident one per CU (128 KB of LDS), so the grid runs in rounds of n_cu workgroups: pick the
     // segment length (multiple of 8) that wastes the least of the last round; ties go to the longer segment, which

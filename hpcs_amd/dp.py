@@ -43,7 +43,10 @@ class FlatGradBucket:
 
     def zero(self):
         self.flat.zero_()
-        for p in self.params:          # re-attach in case something replaced .grad
+        self.check_attached()
+
+    def check_attached(self):
+        for p in self.params:          # every .grad must still alias the flat bucket
             if p.grad is None or p.grad.data_ptr() < self.flat.data_ptr() or \
                     p.grad.data_ptr() >= self.flat.data_ptr() + 4 * self.numel:
                 raise RuntimeError("a parameter's .grad no longer aliases the flat bucket (use bucket.zero(), not "

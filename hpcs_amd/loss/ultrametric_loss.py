@@ -114,7 +114,7 @@ class HypHCSampledFn(torch.autograd.Function):
         loss_sum = torch.empty(1, dtype=torch.float64, device=dev)
         kept = torch.empty(1, dtype=torch.int64, device=dev)
         need_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
-        gxn_raw = torch.zeros(M, E, device=dev) if need_grad else None
+        gxn_raw = torch.empty(M, E, device=dev) if need_grad else None          # zero-filled by the entry point's own zero launch
         gscale_raw = torch.empty(1, dtype=torch.float64, device=dev) if need_grad else None
         dbg = [None, None, None]
         if debug is not None:
@@ -167,7 +167,7 @@ class CosFaceFn(torch.autograd.Function):
         scale, n_levels = ctx.cfg
         M, E = xn.shape
         C = wn.shape[0]
-        gxn = torch.zeros_like(xn)
+        gxn = torch.empty_like(xn)                   # both zero-filled by the entry point
         gwn = torch.empty_like(wn)
         call("hpcs_cosface_bwd", xn, wn, labels, logits, lse, branch_id, n_levels, M, E, C, scale,
              g.reshape(1).contiguous().float(), gxn, gwn)

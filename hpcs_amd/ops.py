@@ -43,11 +43,18 @@ class _ZeroArena:
     SIZE = 1 << 16
 
 
-def zero_arena_reset(device):
+def zero_arena_reset(device, also=None):
+    """Clears the arena; `also` (dp.FlatGradBucket): its flat gradient buffer is cleared by the same launch."""
     a = _ZeroArena
     if a.buf is None or a.buf.device != torch.device(device):
         a.buf = torch.empty(a.SIZE, dtype=torch.float64, device=device)
-    a.buf.zero_()
+    if also is not None and also.flat.is_cuda:
+        also.check_attached()
+        call("hpcs_zero_buffers", a.buf, a.SIZE * 8, also.flat, also.numel * 4, None, 0, None, 0)
+    else:
+        a.buf.zero_()
+        if also is not None:
+            also.zero()
     a.off = 0
 
 

@@ -267,8 +267,7 @@ class HypHCStep(torch.nn.Module):
     # ---- one optimisation step ------------------------------------------------------------------------------------
     def _backward_part(self, points, label, targets, ctx, rot, drop_masks):
         """zero grads -> forward -> losses -> backward (weight gradients on the side stream, joined at the end)."""
-        self.bucket.zero()
-        zero_arena_reset(points.device)        # one memset for all the step's fp64 accumulators
+        zero_arena_reset(points.device, also=self.bucket)   # ONE zero launch: the fp64 accumulator arena + the gradient bucket
         self._prep_cache.begin_step()          # one launch re-lays out every layer's weights (recorded in the first step)
         try:
             if self.side_stream_wgrad and FORWARD_SIDE:          # the backward below is certain to follow and joins the stream

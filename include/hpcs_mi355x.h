@@ -342,8 +342,8 @@ int hpcs_hyphc_bwd(const float* xn, int E, const int64_t* a, const int64_t* p, c
                    double* loss_sum, int64_t* kept, hpcs_stream_t stream);
 /* hyphc_sampled: the training-path form for the device RNG.  Triplets are generated INSIDE the kernel from
  * (class index, per-class plan, seed) -- no index arrays, no sampler/filter pass -- the margin rule `kind` is applied
- * inline, and loss_sum[1], kept[1] and (gxn != NULL) the UNSCALED gradient gxn [M,E] (accumulated into; caller
- * zero-fills) + gscale[1] come out of one sweep.  Positive-row gradients are accumulated in an LDS table per
+ * inline, and loss_sum[1], kept[1] and (gxn != NULL) the UNSCALED gradient gxn [M,E] (zero-filled by the call's own
+ * zero launch, then accumulated into) + gscale[1] come out of one sweep.  Positive-row gradients are accumulated in an LDS table per
  * workgroup.  E must be 16, 32 or 64.  a_dbg/p_dbg/n_dbg (nullable, [T]) receive the generated triplets (tests).
  * T sizes the grid only and must be >= cls_toff[C], the number of triplets the kernel actually samples (read on the
  * device): a captured launch sized for the largest batch serves smaller ones, surplus workgroups exit at once. */
@@ -365,7 +365,7 @@ int hpcs_hyphc_grad_finalize(const float* g, const int64_t* kept, const double* 
  * (next row f2: hierarchical_loss + HierarchicalCosFaceLoss, hpcs/loss/hierarchical_cosface_loss.py:9-87):
  * branch_id [n_levels, C] int32 gives each class its branch per level; loss_row = sum_l -log(sum_{c in branch_l(y)} p_c).
  * fwd writes logits [M,C], loss_rows [M], lse_rows [M].
- * bwd: gxn [M,E] is ACCUMULATED into, gwn [C,E] is overwritten; gloss = device scalar dL/d(mean loss). */
+ * bwd: gxn [M,E] and gwn [C,E] are overwritten (zero-filled by the call, then summed into); gloss = device scalar dL/d(mean loss). */
 int hpcs_cosface_fwd(const float* xn, const float* wn, const int64_t* labels, const int32_t* branch_id, int n_levels,
                      int M, int E, int C, float margin, float scale, float* logits, float* loss_rows,
                      float* lse_rows, hpcs_stream_t stream);
@@ -447,6 +447,9 @@ int hpcs_scale_inplace(float* x, int64_t n, float s, hpcs_stream_t stream);
  * int32[8], zeroed by the caller; [1] word offset, [2] found, [3] expected, [4] differing words, [5] next word,
  * [6] checks so far, [7] [6] at the first mismatch).  hpcs_amd/_lib.py enqueues one watch after every launch when a
  * watch is armed (HPCS_WATCH), also inside hipGraph captures; nothing is allocated. */
+/* One launch zero-fills up to four device buffers (sizes in bytes, multiples of 4; NULL skipped): the library never issues
+ * hipMemset nodes. */
+int hpcs_zero_buffers(void* p0, size_t n0, void* p1, size_t n1, void* p2, size_t n2, void* p3, size_t n3, hpcs_stream_t stream);
 int hpcs_debug_snapshot(const void* src, void* dst, int nbytes, hpcs_stream_t stream);
 int hpcs_debug_watch(const void* watched, const void* shadow, int nbytes, int seq, int32_t* status,
                      hpcs_stream_t stream);
