@@ -591,3 +591,28 @@ def test_train_mode_error_is_no_larger_than_torchs_over_an_ensemble():
         if v["gmean_ratio_hip_over_cpu"] > 1.1:
             bad.append((key, "geometric mean vs torch CPU", v["gmean_ratio_hip_over_cpu"]))
     assert not bad, bad
+
+
+def test_train_mode_gradient_error_is_torchs_over_an_ensemble():
+    """the full-network gradient test holds the HIP path to a fixed 2.5e-2 of an fp64 evaluation -- a
+    2 %-wrong kernel passes where the tensor is noise-dominated.  tests/parity_ensemble.py::run_grads measures, on 6 independent
+    parameter / cloud draws with identical kNN graphs, the L2-relative distance from the fp64 gradients (input cloud + every
+    parameter tensor of the train-mode network) of the HIP path and of the oracle's torch op sequence (= the reference's) in
+    fp32 on the CPU and on this GPU.  Measured r03 (profiles/r03_grad_ensemble.json): the quantity is heavy-tailed for EVERY
+    realisation -- all-parameter error per draw 1.2e-3 ... 1.1e-1 for HIP, 1.3e-3 ... 4.3e-2 for torch-CPU, 1.7e-3 ... 3.1e-2
+    for torch-GPU; geometric mean of HIP / max(both) 0.83, of HIP / torch-GPU 1.10; the median tensor is CLOSER to fp64 on the HIP
+    path than on torch-GPU (0.51); 10 of 294 tensors further than twice both.  Bars (regression guard with that spread in mind):
+
+        geometric mean over the draws of  err_all(HIP) / max(err_all(torch CPU), err_all(torch GPU))  <= 1.3
+        no single draw above 4x, at most 8 % of the tensors further than twice both torch realisations."""
+    import math
+    import parity_ensemble as PE
+    res = PE.run_grads(seeds=6, E=32, verbose=False)
+    REPORT["train_mode_gradient_ensemble_summary"] = res["summary"]
+    ratios = [r["hip"]["all_l2"] / max(r["torch_cpu_fp32"]["all_l2"], r["torch_gpu_fp32"]["all_l2"]) for r in res["runs"]]
+    gm = math.exp(sum(math.log(v) for v in ratios) / len(ratios))
+    assert gm <= 1.3, (gm, ratios)
+    assert max(ratios) <= 4.0, ratios
+    far = res["summary"]["tensors_further_than_2x_both"]
+    assert far["count"] <= 0.08 * far["of"], far
+    assert all(r["tensors"] >= 40 for r in res["runs"])
