@@ -887,7 +887,7 @@ constexpr int NB_LD = 128 * NB_PIECES / 256;   // pieces per thread and operand
 __global__ __launch_bounds__(256, NB_BK == 16 ? 4 : 2) void gemm_nt_big_kernel(
     const float* __restrict__ G, int ldg, int64_t sGo, int64_t sGi, const float* __restrict__ X, int ldx, int64_t sXo,
     int64_t sXi, int M, int Kx, int Nc, int n_inner, int n_batch, int chunk, int units_per_batch, int nsplit,
-    float* __restrict__ part, int tilesM, int tilesK, int vecG, int vecX) {
+    float* __restrict__ part, int tilesM, int tilesK, int vecG, int vecX, NtFuse fuse) {
     extern __shared__ __attribute__((aligned(16))) float lds[];        // 2 * NB_BK * 2 * NB_P floats (dynamic: 66 KB at 32-deep steps)
     float (*As)[NB_BK][NB_P] = reinterpret_cast<float (*)[NB_BK][NB_P]>(lds);
     float (*Bs)[NB_BK][NB_P] = reinterpret_cast<float (*)[NB_BK][NB_P]>(lds + 2 * NB_BK * NB_P);
@@ -968,6 +968,31 @@ __global__ __launch_bounds__(256, NB_BK == 16 ? 4 : 2) void gemm_nt_big_kernel(
         if (have_next) lstore(buf ^ 1);
         __syncthreads();
         buf ^= 1;
+    }
+    if (fuse.tickets != nullptr) {
+        // In-launch split reduction (nt_fused_reduce), one 64 x 64 QUARTER of the tile at a time: quarter q is wave q's four
+        // accumulators, staged dense in the (dead) operand LDS; partials, tickets and the final sum are per quarter tile
+        // (tile * 4 + q of 4 * tiles).  Quarters that lie entirely in the padding are skipped by every workgroup alike.
+        float* tl = lds;                                       // 64 x 64 floats + the arrival flag behind them
+        for (int q = 0; q < 4; ++q) {
+            const int qm = q >> 1, qn = q & 1;
+            const int m0q = m0 + qm * 64, x0q = x0 + qn * 64;
+            if (m0q >= M || x0q >= Kx) continue;               // (uniform over the workgroup)
+            __syncthreads();                                   // main loop / previous quarter done with the LDS
+            if (wave == q) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            tl[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * 64 + j * 32 + lr] = live[i][j] ? acc[i][j][r] : 0.f;
+            }
+            __syncthreads();
+            nt_fused_reduce<256, 64, 64>(fuse, part, tl, nsplit, split, tile * 4 + q, tilesM * tilesK * 4, M, Kx, m0q, x0q,
+                                         reinterpret_cast<int*>(tl + 64 * 64));
+        }
+        return;
     }
     float* P = part + (int64_t)split * M * Kx;
 #pragma unroll
@@ -1242,7 +1267,7 @@ extern "C" size_t hpcs_gemm_nt_tickets(int M, int Kx, int Nc, int n_outer, int n
     const bool two = sr_two_level(p.nsplit, (int64_t)M * Kx);
     const int slice_len = two ? hpcs_cdiv(p.nsplit, SR_SLICES) : p.nsplit;
     const int slices = hpcs_cdiv(p.nsplit, slice_len);
-    return (size_t)p.tilesM * p.tilesK * (slices + 1);
+    return (size_t)p.tilesM * p.tilesK * (p.tile == 128 ? 4 : 1) * (slices + 1);
 }
 
 static int gemm_nt_impl(const float* G, int ldg, int64_t strideG_o, int64_t strideG_i, const float* X, int ldx,
@@ -1266,11 +1291,16 @@ static int gemm_nt_impl(const float* G, int ldg, int64_t strideG_o, int64_t stri
     float* stage = (float*)ws + (size_t)p.nsplit * ne;
     const bool edge = p.tilesM * p.tilesK == 1 && M <= NE_T && Kx <= NE_T;
     NtFuse fuse{nullptr, stage, dW, lddw, accumulate, slice_len, slices, 0u, 0u};
-    if (tickets && n_tickets < (size_t)p.tilesM * p.tilesK * (slices + 1)) return HPCS_ERR_WORKSPACE;
-    if (tickets && p.tile != 128) {           // (gemm_nt_big_kernel writes plain partials: split_reduce launches follow)
-        const size_t te = edge ? (size_t)NE_T * NE_T : (size_t)p.tile * p.tile;
-        const size_t pb = (size_t)p.nsplit * p.tilesM * p.tilesK * te * sizeof(float);
-        const size_t sb = (size_t)slices * p.tilesM * p.tilesK * te * sizeof(float);
+    const size_t rtiles = (size_t)p.tilesM * p.tilesK * (p.tile == 128 ? 4 : 1);      // reduction units: 64 x 64 quarters of a big tile
+    if (tickets && n_tickets < rtiles * (slices + 1)) return HPCS_ERR_WORKSPACE;
+    // gemm_nt_big_kernel can reduce its splits in the launch as well (64 x 64 quarter tiles through nt_fused_reduce), but the four
+    // staged quarters + tickets cost it ~75 us (392 / 687 us against 316 / 614 us + two split_reduce launches) and the step
+    // is the same within noise (10.08-10.10 vs 10.05-10.13 ms): off by default, HPCS_NT_BIG_FUSED=1 turns it on.
+    static const bool big_fused = [] { const char* e = getenv("HPCS_NT_BIG_FUSED"); return e ? atoi(e) != 0 : false; }();
+    if (tickets && (p.tile != 128 || big_fused)) {
+        const size_t te = edge ? (size_t)NE_T * NE_T : (p.tile == 128 ? (size_t)64 * 64 : (size_t)p.tile * p.tile);
+        const size_t pb = (size_t)p.nsplit * rtiles * te * sizeof(float);
+        const size_t sb = (size_t)slices * rtiles * te * sizeof(float);
         if (pb >= (1ull << 31) || sb >= (1ull << 31)) return HPCS_ERR_UNSUPPORTED;
         fuse.tickets = tickets;
         fuse.stage = (float*)((char*)ws + pb);
@@ -1284,7 +1314,7 @@ static int gemm_nt_impl(const float* G, int ldg, int64_t strideG_o, int64_t stri
     else if (p.tile == 128)
         hipLaunchKernelGGL(gemm_nt_big_kernel, dim3((unsigned)blocks), dim3(256), nb_lds_bytes(), st, G, ldg, strideG_o, strideG_i, X, ldx,
                            strideX_o, strideX_i, M, Kx, Nc, n_inner, nb, p.chunk, p.units_per_batch, p.nsplit, (float*)ws,
-                           p.tilesM, p.tilesK, vecG, vecX);
+                           p.tilesM, p.tilesK, vecG, vecX, fuse);
     else
         hipLaunchKernelGGL((gemm_nt_kernel<64, 64, NT_BKC, 2, 2>), dim3((unsigned)blocks), dim3(256), 0, st, G, ldg,
                            strideG_o, strideG_i, X, ldx, strideX_o, strideX_i, M, Kx, Nc, n_inner, nb, p.chunk,
