@@ -1085,6 +1085,17 @@ __global__ __launch_bounds__(SB_THREADS) void hyphc_sampled4_kernel(
         // (indices are re-broadcast where they are needed -- two DPP moves -- instead of living in 12 registers across the
         // scalar phase: the kernel sits at the 128-register cap of four waves per SIMD)
 #define BQ(v, q) ((q) == 0 ? grp_bcast<0>(v) : (q) == 1 ? grp_bcast<1>(v) : (q) == 2 ? grp_bcast<2>(v) : grp_bcast<3>(v))
+        // eight ring rows (two per wave-instruction at E = 32) -> row-contiguous global atomics
+#define HPCS_RING_FLUSH8                                                                                   \
+        {                                                                                                  \
+            constexpr int RPI_ = 64 / E;                                                                   \
+            _Pragma("unroll") for (int r_ = 0; r_ < EPL; ++r_) {                                           \
+                const int slot_ = (qh + r_ * RPI_ + lane / E) & 15, e_ = lane % E;                         \
+                atomicAdd(gxn + (unsigned)(qid[slot_] * E + e_), qrows[slot_ * LD + e_]);                  \
+            }                                                                                              \
+            qh = (qh + 8) & 15;                                                                            \
+            qn -= 8;                                                                                       \
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             IO::load(xn, E, BQ(ip_own, q), s, P[q]);
@@ -1158,16 +1169,27 @@ __global__ __launch_bounds__(SB_THREADS) void hyphc_sampled4_kernel(
                 const int ia = BQ(ia_own, q), in = BQ(in_own, q);
                 const bool moved = lv && (ia != cur || ia != ia_have);
                 if (__builtin_amdgcn_ballot_w64(moved) != 0ull) {           // once per ~k_c triplets and group
+                    // a finished anchor's gradient leaves through the ring too (whole rows per atomic instruction)
+                    const bool fl = moved && ia != cur && cur >= 0;
+                    const unsigned long long fbal = __ballot(fl);
+                    if (fbal != 0ull) {
+                        if (fl) {
+                            const int rank_q = __popcll(fbal & ((1ull << (lane & ~7)) - 1ull)) >> 3;
+                            const int slot = (qh + qn + rank_q) & 15;
+                            float* qr = qrows + slot * LD + s * EPL;
+#pragma unroll
+                            for (int j = 0; j < EPL; ++j) qr[j] = acc_a[j];
+                            if (s == 0) qid[slot] = cur;
+                        }
+                        qn += __popcll(fbal) >> 3;
+                        if (qn >= 8) { HPCS_RING_FLUSH8 }
+                    }
                     if (moved) {
                         if (ia != ia_have) {                                // (the anchor changed inside the batch)
                             IO::load(xn, E, ia, s, av);
                             ia_have = ia;
                         }
                         if (ia != cur) {
-                            if (cur >= 0) {
-#pragma unroll
-                                for (int j = 0; j < EPL; ++j) atomicAdd(gxn + (unsigned)(cur * E + s * EPL + j), acc_a[j]);
-                            }
                             cur = ia;
 #pragma unroll
                             for (int j = 0; j < EPL; ++j) acc_a[j] = 0.f;
@@ -1240,6 +1262,22 @@ __global__ __launch_bounds__(SB_THREADS) void hyphc_sampled4_kernel(
             }
         }
     }
+    if (GRAD) {                                                         // every group's last anchor joins the ring
+        const bool fl = cur >= 0;
+        const unsigned long long fbal = __ballot(fl);
+        if (fbal != 0ull) {
+            if (fl) {
+                const int rank_q = __popcll(fbal & ((1ull << (lane & ~7)) - 1ull)) >> 3;
+                const int slot = (qh + qn + rank_q) & 15;
+                float* qr = qrows + slot * LD + s * EPL;
+#pragma unroll
+                for (int j = 0; j < EPL; ++j) qr[j] = acc_a[j];
+                if (s == 0) qid[slot] = cur;
+            }
+            qn += __popcll(fbal) >> 3;
+            if (qn >= 8) { HPCS_RING_FLUSH8 }
+        }
+    }
     if (GRAD && qn > 0) {                                               // the ring's last (fewer than eight) rows
         constexpr int RPI = 64 / E;
 #pragma unroll
@@ -1248,10 +1286,6 @@ __global__ __launch_bounds__(SB_THREADS) void hyphc_sampled4_kernel(
             const int slot = (qh + t_) & 15;
             if (t_ < qn) atomicAdd(gxn + (unsigned)(qid[slot] * E + e), qrows[slot * LD + e]);
         }
-    }
-    if (GRAD && cur >= 0) {
-#pragma unroll
-        for (int j = 0; j < EPL; ++j) atomicAdd(gxn + (unsigned)(cur * E + s * EPL + j), acc_a[j]);
     }
     const double lt = hpcs_block_sum<double>(acc_loss, red);
     if (threadIdx.x == 0 && lt != 0.0) atomicAdd(loss_sum, lt);
@@ -1276,6 +1310,7 @@ __global__ __launch_bounds__(SB_THREADS) void hyphc_sampled4_kernel(
     }
 }
 #undef BQ
+#undef HPCS_RING_FLUSH8
 
 template <bool BWD>
 int launch_hyphc(const float* xn, int E, const int64_t* a, const int64_t* p, const int64_t* n, const int64_t* count,
