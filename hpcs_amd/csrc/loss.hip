@@ -2051,8 +2051,11 @@ extern "C" int hpcs_hyphc_sampled(const float* xn, const int64_t* labels, const 
     const bool grad = gxn != nullptr;
     const int LD = E + 8;
     const size_t slab_bytes = (size_t)(SB_THREADS / 64) * (16 * LD + 16) * sizeof(float);     // negative-row rings + ids
-    // one 1024-thread workgroup per CU (forcing 8 waves/SIMD spills: measured 2.4x slower): 128 KB of LDS
-    int RC = grad ? (int)((128 * 1024 - slab_bytes) / ((E + 8) * sizeof(float))) : 0;     // rows of the positive table
+    // one 1024-thread workgroup per CU (forcing 8 waves/SIMD spills: measured 2.4x slower)
+    // 156 of the CU's 160 KB (gfx950): 731 table rows at E = 32 instead of 556 at the 128 KB this was sized for -- fewer positives
+    // take the global-atomic route (-1.2 % kernel time on the bench's imbalanced labels)
+    static const size_t lds_budget = [] { const char* e = getenv("HPCS_SAMPLED_LDS_KB"); return (size_t)(e ? atoi(e) : 156) * 1024; }();
+    int RC = grad ? (int)((lds_budget - slab_bytes) / ((E + 8) * sizeof(float))) : 0;     // rows of the positive table
     if (RC > 1024) RC = 1024;
     const size_t lds = (size_t)RC * (E + 8) * sizeof(float) + slab_bytes;
 #define HPCS_SAMPLED_LAUNCH(KERNEL, EPL)                                                                              \
