@@ -637,7 +637,7 @@ __device__ __forceinline__ void lds_add_row(float* base, const float (&v)[EPL]) 
 
 constexpr int SB_THREADS = 1024;
 constexpr int SB_GROUPS = SB_THREADS / SUB;      // 128
-constexpr int SB_SEG_MAX = 128;                  // triplets per 8-lane group: chosen per launch (multiple of 8) so that the
+constexpr int SB_SEG_MAX = 256;                  // triplets per 8-lane group: chosen per launch (multiple of 8) so that the
 constexpr int SB_SEG_MIN = 16;                   // workgroup count fills whole rounds of one-workgroup-per-CU residency
 
 __device__ __forceinline__ int class_of(const int64_t* __restrict__ toff, int C, int64_t t) {
@@ -878,10 +878,35 @@ __global__ __launch_bounds__(SB_THREADS) void hyphc_sampled_kernel(
 #pragma unroll
                         for (int j = 0; j < EPL; ++j) gp[j] = c0 * av[j] + c2 * nv[j];
                         lds_add_row<EPL>(cache + cpos * TS + s, gp);
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < EPL; ++j) atomicAdd(gxn + (unsigned)(ip * E + s * EPL + j), c0 * av[j] + c2 * nv[j]);
                     }
+                }
+                // a positive beyond the table leaves through the ring, like a negative row (see hyphc_sampled4_kernel)
+                bool ov_flush = false;
+                {
+                    const bool ov = cpos == -1;
+                    const unsigned long long obal = __ballot(ov);
+                    if (obal != 0ull) {
+                        if (ov) {
+                            const int rank = __popcll(obal & ((1ull << (lane & ~7)) - 1ull)) >> 3;
+                            const int slot = (qh + qn + rank) & 15;
+                            float* qr = qrows + slot * LD + s * EPL;
+#pragma unroll
+                            for (int j = 0; j < EPL; ++j) qr[j] = c0 * av[j] + c2 * nv[j];
+                            if (s == 0) qid[slot] = ip;
+                        }
+                        qn += __popcll(obal) >> 3;
+                        ov_flush = qn >= 8;
+                    }
+                }
+                if (ov_flush) {
+                    constexpr int RPI = 64 / E;
+#pragma unroll
+                    for (int r = 0; r < EPL; ++r) {
+                        const int slot = (qh + r * RPI + lane / E) & 15, e = lane % E;
+                        atomicAdd(gxn + (unsigned)(qid[slot] * E + e), qrows[slot * LD + e]);
+                    }
+                    qh = (qh + 8) & 15;
+                    qn -= 8;
                 }
                 // negative rows: a CU issues one 256-byte atomic wave-instruction per ~120 cycles, and this kernel is bound by
                 // exactly that.  Kept rows are therefore packed into a wave-private LDS ring (16 rows) and leave in groups
@@ -2028,7 +2053,7 @@ extern "C" int hpcs_hyphc_sampled(const float* xn, const int64_t* labels, const 
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
             v = 256;
         n_cu = v;
-        const char* e = getenv("HPCS_SAMPLED_SEG");          // tuning override (multiple of 8 in [8, 128])
+        const char* e = getenv("HPCS_SAMPLED_SEG");          // tuning override (multiple of 8 in [8, 256])
         seg_env = e ? atoi(e) : 0;
     }
     int seg_len = SB_SEG_MAX;
@@ -2038,7 +2063,9 @@ extern "C" int hpcs_hyphc_sampled(const float* xn, const int64_t* labels, const 
         int64_t best = INT64_MAX;
         for (int sl = SB_SEG_MAX; sl >= SB_SEG_MIN; sl -= 8) {
             const int64_t blocks = (T + (int64_t)SB_GROUPS * sl - 1) / ((int64_t)SB_GROUPS * sl);
-            const int64_t cost = ((blocks + n_cu - 1) / n_cu) * sl;
+            // rounds x (segment + a workgroup's fixed cost: zeroing and flushing the positive table, ~11 segment units -- fitted to
+            // 104 vs 176 at T = 16.9 M: 1.258 vs 1.227 ms)
+            const int64_t cost = ((blocks + n_cu - 1) / n_cu) * (sl + 11);
             if (cost < best) { best = cost; seg_len = sl; }
         }
     }
