@@ -967,7 +967,13 @@ __global__ __launch_bounds__(TPB) void vn_bwd_apply_shared_vec_kernel(
         }
     }
     const int64_t l = ((int64_t)blockIdx.x * TPB + threadIdx.x) * 4;
-    if (l >= L) return;
+    const bool dead = l >= L;                                  // (stays for the wave-wide transposed atomics at the end)
+    float gdsum[3][4];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gdsum[a][q] = 0.f;
+    if (!dead) {
     const double count = (double)B * (double)L;
     const bool bn = flags & HPCS_VN_BN;
     const float* Pb = PD + ((int64_t)b * Ctot * 3) * L + l;
@@ -979,11 +985,6 @@ __global__ __launch_bounds__(TPB) void vn_bwd_apply_shared_vec_kernel(
         const float4 v = (flags & HPCS_VN_LRELU) ? *reinterpret_cast<const float4*>(Pb + ((int64_t)Cout * 3 + a) * L) : make_float4(0.f, 0.f, 0.f, 0.f);
         dsh[a][0] = v.x; dsh[a][1] = v.y; dsh[a][2] = v.z; dsh[a][3] = v.w;
     }
-    float gdsum[3][4];
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) gdsum[a][q] = 0.f;
     float4 pn[3], gn[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -1024,10 +1025,27 @@ __global__ __launch_bounds__(TPB) void vn_bwd_apply_shared_vec_kernel(
         for (int a = 0; a < 3; ++a)
             *reinterpret_cast<float4*>(Ob + ((int64_t)c * 3 + a) * L) = make_float4(o[a][0], o[a][1], o[a][2], o[a][3]);
     }
+    }   // !dead
+    // The shared direction's gradient is summed over the channel chunks with float atomics.  A lane owns four CONSECUTIVE
+    // positions, so adding them straight from the registers is four instructions of 4-byte pieces 16 bytes apart; transposed
+    // through a wave-private LDS patch every instruction covers 256 contiguous bytes instead (the shape the atomic units
+    // process at full rate -- the same finding as in the sampled HypHC kernel, DESIGN.md section 8 "Round 3").
+    __shared__ float tp[TPB / 64][3][256];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) atomicAdd(Ob + ((int64_t)Cout * 3 + a) * L + q, gdsum[a][q]);
+        for (int q = 0; q < 4; ++q) tp[wv][a][lane * 4 + q] = gdsum[a][q];
+    __builtin_amdgcn_s_waitcnt(0xC07F);                       // lgkmcnt(0); the patch is wave-private
+    const int64_t l_wave = l - (int64_t)lane * 4;             // first position of this wave
+    float* Od = GPD + ((int64_t)b * Ctot * 3) * L + (int64_t)Cout * 3 * L + l_wave;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int pos = q * 64 + lane;
+            if (l_wave + pos < L) atomicAdd(Od + (int64_t)a * L + pos, tp[wv][a][pos]);
+        }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
