@@ -884,7 +884,10 @@ __global__ __launch_bounds__(1024) void split_reduce_kernel(const float* __restr
 constexpr int NB_BK = HPCS_NB_BK, NB_P = 132;
 constexpr int NB_PIECES = NB_BK / 4;          // 16-byte pieces per operand row and step
 constexpr int NB_LD = 128 * NB_PIECES / 256;   // pieces per thread and operand
-__global__ __launch_bounds__(256, NB_BK == 16 ? 4 : 2) void gemm_nt_big_kernel(
+// FUSED: the in-launch split reduction (off by default) -- its eight 16-byte partial loads in flight next to the 64 live
+// accumulators spill at 128 registers, so that instantiation is built for two workgroups per CU (256 registers).
+template <bool FUSED>
+__global__ __launch_bounds__(256, (NB_BK == 16 && !FUSED) ? 4 : 2) void gemm_nt_big_kernel(
     const float* __restrict__ G, int ldg, int64_t sGo, int64_t sGi, const float* __restrict__ X, int ldx, int64_t sXo,
     int64_t sXi, int M, int Kx, int Nc, int n_inner, int n_batch, int chunk, int units_per_batch, int nsplit,
     float* __restrict__ part, int tilesM, int tilesK, int vecG, int vecX, NtFuse fuse) {
@@ -969,7 +972,7 @@ __global__ __launch_bounds__(256, NB_BK == 16 ? 4 : 2) void gemm_nt_big_kernel(
         __syncthreads();
         buf ^= 1;
     }
-    if (fuse.tickets != nullptr) {
+    if constexpr (FUSED) {
         // In-launch split reduction (nt_fused_reduce), one 64 x 64 QUARTER of the tile at a time: quarter q is wave q's four
         // accumulators, staged dense in the (dead) operand LDS; partials, tickets and the final sum are per quarter tile
         // (tile * 4 + q of 4 * tiles).  Quarters that lie entirely in the padding are skipped by every workgroup alike.
@@ -992,26 +995,28 @@ __global__ __launch_bounds__(256, NB_BK == 16 ? 4 : 2) void gemm_nt_big_kernel(
             nt_fused_reduce<256, 64, 64>(fuse, part, tl, nsplit, split, tile * 4 + q, tilesM * tilesK * 4, M, Kx, m0q, x0q,
                                          reinterpret_cast<int*>(tl + 64 * 64));
         }
-        return;
-    }
-    float* P = part + (int64_t)split * M * Kx;
+    } else {
+        (void)fuse;
+        float* P = part + (int64_t)split * M * Kx;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = x0 + wn * 64 + j * 32 + lr;
+            for (int j = 0; j < 2; ++j) {
+                const int col = x0 + wn * 64 + j * 32 + lr;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                if (row < M && col < Kx) P[(int64_t)row * Kx + col] = acc[i][j][r];
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    if (row < M && col < Kx) P[(int64_t)row * Kx + col] = acc[i][j][r];
+                }
             }
-        }
+    }
 }
 
 static size_t nb_lds_bytes() {
     static const size_t bytes = [] {
         const size_t b = (size_t)2 * NB_BK * 2 * NB_P * sizeof(float);
-        (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
+        (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
+        (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
         return b;
     }();
     return bytes;
@@ -1311,9 +1316,13 @@ static int gemm_nt_impl(const float* G, int ldg, int64_t strideG_o, int64_t stri
         hipLaunchKernelGGL(gemm_nt_edge_kernel, dim3((unsigned)blocks), dim3(256), 0, st, G, ldg, strideG_o, strideG_i, X, ldx,
                            strideX_o, strideX_i, M, Kx, Nc, n_inner, nb, p.chunk, p.units_per_batch, p.nsplit, (float*)ws, vecG,
                            vecX, fuse);
+    else if (p.tile == 128 && fuse.tickets)
+        hipLaunchKernelGGL(gemm_nt_big_kernel<true>, dim3((unsigned)blocks), dim3(256), nb_lds_bytes(), st, G, ldg, strideG_o, strideG_i, X,
+                           ldx, strideX_o, strideX_i, M, Kx, Nc, n_inner, nb, p.chunk, p.units_per_batch, p.nsplit, (float*)ws,
+                           p.tilesM, p.tilesK, vecG, vecX, fuse);
     else if (p.tile == 128)
-        hipLaunchKernelGGL(gemm_nt_big_kernel, dim3((unsigned)blocks), dim3(256), nb_lds_bytes(), st, G, ldg, strideG_o, strideG_i, X, ldx,
-                           strideX_o, strideX_i, M, Kx, Nc, n_inner, nb, p.chunk, p.units_per_batch, p.nsplit, (float*)ws,
+        hipLaunchKernelGGL(gemm_nt_big_kernel<false>, dim3((unsigned)blocks), dim3(256), nb_lds_bytes(), st, G, ldg, strideG_o, strideG_i, X,
+                           ldx, strideX_o, strideX_i, M, Kx, Nc, n_inner, nb, p.chunk, p.units_per_batch, p.nsplit, (float*)ws,
                            p.tilesM, p.tilesK, vecG, vecX, fuse);
     else
         hipLaunchKernelGGL((gemm_nt_kernel<64, 64, NT_BKC, 2, 2>), dim3((unsigned)blocks), dim3(256), 0, st, G, ldg,
