@@ -20,6 +20,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# this process is the benchmark and nothing else: opt in to the step driver's one-off gc.collect() + gc.freeze() (CPython's
+# first full collection of the start-up heap otherwise lands as a 40-100 ms host stall inside a 20-step window)
+os.environ.setdefault("HPCS_GC_FREEZE", "1")
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TF = 157.3     # MI355X_MICROARCH.md: fp32 matrix peak (v_mfma_f32_32x32x2_f32)
@@ -245,6 +248,25 @@ def knn_steady_state(dev, N, k, B=4096, D=3, reps=5):
             "clouds_per_s": round(B / t)}
 
 
+def launch_ranks(n):
+    """One process per GPU: `python -m torch.distributed.run --nnodes=1 --nproc-per-node n` on this script with the same
+    arguments, rendezvous on 127.0.0.1 at a free port.  The children are fresh interpreters (subprocess); the parent only
+    waits, so nothing that has initialised the GPU is ever replaced by another program.  Returns the launcher's exit code;
+    rank 0's JSON line reaches stdout through the inherited descriptor."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, min(len(os.sched_getaffinity(0)) // n, 16))))
+    print(f"[bench] launching {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -280,6 +302,12 @@ def main():
     workload += f"; eucl/hyp_embedding={args.embedding}, vn_dgcnn_partseg + ExpMap + miner + HypHC + " \
                 f"{'hierarchical ' if args.hierarchical else ''}CosFace + RAdam"
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: this process (which has not touched the GPU) starts the N ranks
+        # itself -- fresh child processes under torch.distributed.run, never an exec -- relays their output and exits
+        # with their status
+        raise SystemExit(launch_ranks(args.gpus))
+
     from hpcs_amd import _lib
     from hpcs_amd.dp import broadcast_parameters, init_distributed
     import torch.distributed as dist
@@ -290,8 +318,7 @@ def main():
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
     torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)) // max(local_world, 1), 16)))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher's WORLD_SIZE is {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (hpcs_amd has no CPU fallback)")
     if os.environ.get("HPCS_SINGLE_DEVICE_REHEARSAL"):      # several ranks sharing cuda:0 (gloo), code-path rehearsal only

@@ -221,6 +221,30 @@ def _call(name, *args):
     return rc
 
 
+GRAPH_NODE_TYPES = ("kernel", "memcpy", "memset", "host", "child_graph", "empty", "wait_event", "event_record",
+                    "ext_sem_signal", "ext_sem_wait", "mem_alloc", "mem_free", "memcpy_from_symbol", "memcpy_to_symbol",
+                    "batch_mem_op", "other")
+
+
+def graph_census(cuda_graph):
+    """{node type: count} of a captured torch.cuda.CUDAGraph built with keep_graph=True (hpcs_debug_graph_census walks
+    hipGraphGetNodes / hipGraphNodeGetType, child graphs included).  None when this torch cannot hand out the raw graph."""
+    raw = getattr(cuda_graph, "raw_cuda_graph", None)
+    if raw is None:
+        return None
+    try:
+        ptr = int(raw())
+    except Exception:                                   # noqa: BLE001 -- built without keep_graph / older torch
+        return None
+    counts = (ctypes.c_int64 * 16)()
+    rc = _fn("hpcs_debug_graph_census")(ctypes.c_void_p(ptr), ctypes.cast(counts, ctypes.c_void_p))
+    if rc < 0:
+        raise HpcsNativeError(f"hpcs_debug_graph_census failed (status {rc})")
+    out = {n: int(c) for n, c in zip(GRAPH_NODE_TYPES, counts) if c}
+    out["total"] = int(rc)
+    return out
+
+
 def exported_symbols_declared_in_header():
     """Names declared in include/hpcs_mi355x.h (used by the ABI test)."""
     return sorted(SIGNATURES)

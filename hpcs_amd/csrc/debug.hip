@@ -66,3 +66,43 @@ extern "C" int hpcs_zero_buffers(void* p0, size_t n0, void* p1, size_t n1, void*
                                  hpcs_stream_t stream) {
     return hpcs_zero_async((hipStream_t)stream, p0, n0, p1, n1, p2, n2, p3, n3);
 }
+
+// Node census of a captured hipGraph: counts[t] = number of nodes of hipGraphNodeType t (0 kernel, 1 memcpy,
+// 2 memset, 3 host, 4 child graph, 5 empty, ...; types >= 15 are counted in counts[15]), child graphs walked recursively.
+// The step driver refuses a capture that holds a memset node: on this runtime those lose their arguments once a second
+// graph is instantiated (DESIGN.md "The stray store"); torch ops inside the captured step could still emit them.
+// Host-only, no launch.  Returns the total node count or a negative status.
+static int graph_census(hipGraph_t graph, int64_t* counts, int depth) {
+    if (depth > 8) return HPCS_ERR_SHAPE;
+    size_t n = 0;
+    hipError_t e = hipGraphGetNodes(graph, nullptr, &n);
+    if (e != hipSuccess) return HPCS_ERR_HIP - (int)e;
+    if (n == 0) return 0;
+    hipGraphNode_t* nodes = (hipGraphNode_t*)malloc(n * sizeof(hipGraphNode_t));
+    if (!nodes) return HPCS_ERR_SHAPE;
+    e = hipGraphGetNodes(graph, nodes, &n);
+    int total = 0;
+    for (size_t i = 0; e == hipSuccess && i < n; ++i) {
+        hipGraphNodeType t;
+        e = hipGraphNodeGetType(nodes[i], &t);
+        if (e != hipSuccess) break;
+        counts[(int)t < 15 ? (int)t : 15] += 1;
+        ++total;
+        if (t == hipGraphNodeTypeGraph) {
+            hipGraph_t child = nullptr;
+            e = hipGraphChildGraphNodeGetGraph(nodes[i], &child);
+            if (e != hipSuccess) break;
+            const int sub = graph_census(child, counts, depth + 1);
+            if (sub < 0) { free(nodes); return sub; }
+            total += sub;
+        }
+    }
+    free(nodes);
+    return e == hipSuccess ? total : HPCS_ERR_HIP - (int)e;
+}
+
+extern "C" int hpcs_debug_graph_census(void* graph, int64_t* counts16) {
+    if (!graph || !counts16) return HPCS_ERR_NULL;
+    for (int i = 0; i < 16; ++i) counts16[i] = 0;
+    return graph_census((hipGraph_t)graph, counts16, 0);
+}

@@ -214,6 +214,47 @@ __global__ void hyp_lca_bwd_kernel(const float* __restrict__ a, const float* __r
     }
 }
 
+// Backward of the COORDINATE output (hyp_lca(a, b, return_coord=True), hpcs/distances/lca.py:37-52 is differentiable in the
+// reference).  p = F(q) c with c = al*a + be*b the centre of the geodesic's circle (G [al; be] = h, G the Gram matrix of
+// (a, b), h = ((1+aa)/2, (1+bb)/2)), q = |c|^2, F(q) = 1 - sqrt(1 - 1/q).  With g = dL/dp:
+//   dL/dc = F g + 2 F'(q) (g.c) c,  dL/dal = dL/dc . a,  dL/dbe = dL/dc . b   (c.a = h1, c.b = h2 by construction),
+//   lam = G^-1 (dL/dal, dL/dbe)   (adjoint of the 2x2 solve: dL/dh = lam, dL/dG = -lam [al be]),
+//   dL/da = al dL/dc + lam1 (1 - 2 al) a - (lam1 be + lam2 al) b,   dL/db symmetric.   fp64 scalars, like the forward.
+__global__ void hyp_lca_coord_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                         const float* __restrict__ gcoord, int64_t rows, int E, float* __restrict__ ga,
+                                         float* __restrict__ gb) {
+    ROW_PROLOGUE();
+    float aaf = 0.f, abf = 0.f, bbf = 0.f, gaf = 0.f, gbf = 0.f;
+    for (int i = s; i < E; i += SUB) {
+        const float x = a[base + i], y = b[base + i], g = gcoord[base + i];
+        aaf += x * x; abf += x * y; bbf += y * y; gaf += g * x; gbf += g * y;
+    }
+    aaf = sub_sum(aaf); abf = sub_sum(abf); bbf = sub_sum(bbf); gaf = sub_sum(gaf); gbf = sub_sum(gbf);
+    const LcaScalars q = lca_scalars(aaf, abf, bbf);
+    if (!live) return;
+    double F = 0.0, k_c = 0.0, al = 0.0, be = 0.0, lam1 = 0.0, lam2 = 0.0;
+    if (q.m > 0.0 && q.C2 > 1.0) {
+        al = (q.bb * (1 + q.aa) - q.ab * (1 + q.bb)) / (2.0 * q.det);
+        be = (q.aa * (1 + q.bb) - q.ab * (1 + q.aa)) / (2.0 * q.det);
+        const double root = sqrt(1.0 - 1.0 / q.C2);
+        F = q.m / sqrt(q.C2);                                     // = 1 - root, without the cancellation
+        const double dF = -1.0 / (2.0 * q.C2 * q.C2 * root);
+        const double g_c = al * (double)gaf + be * (double)gbf;   // g . c
+        k_c = 2.0 * dF * g_c;                                     // dL/dc = F g + k_c c
+        const double d_al = F * (double)gaf + k_c * 0.5 * (1 + q.aa);
+        const double d_be = F * (double)gbf + k_c * 0.5 * (1 + q.bb);
+        lam1 = (q.bb * d_al - q.ab * d_be) / q.det;
+        lam2 = (q.aa * d_be - q.ab * d_al) / q.det;
+    }
+    const double cross = lam1 * be + lam2 * al;
+    for (int i = s; i < E; i += SUB) {
+        const double x = a[base + i], y = b[base + i], g = gcoord[base + i];
+        const double gc = F * g + k_c * (al * x + be * y);
+        ga[base + i] = (float)(al * gc + lam1 * (1.0 - 2.0 * al) * x - cross * y);
+        gb[base + i] = (float)(be * gc + lam2 * (1.0 - 2.0 * be) * y - cross * x);
+    }
+}
+
 // ---- a15 / a8 dense matrices (API completeness; the training path never builds them) ----------------------
 __device__ __forceinline__ float hyperbolic_sim_pair(const float* __restrict__ xr, const float* __restrict__ yr, int E, float eps) {
     const float maxn = 1.f - BALL_EPS_F32;
@@ -460,6 +501,16 @@ extern "C" int hpcs_hyp_lca_bwd(const float* a, const float* b, const float* gdi
     if (!ROW_ARGS_OK(rows, E)) return HPCS_ERR_SHAPE;
     if (rows == 0) return HPCS_OK;
     hipLaunchKernelGGL(hyp_lca_bwd_kernel, ROW_GRID(rows), a, b, gdist, rows, E, ga, gb);
+    HPCS_CHECK_LAUNCH();
+    return HPCS_OK;
+}
+
+extern "C" int hpcs_hyp_lca_coord_bwd(const float* a, const float* b, const float* gcoord, int64_t rows, int E, float* ga,
+                                      float* gb, hpcs_stream_t stream) {
+    if (!a || !b || !gcoord || !ga || !gb) return HPCS_ERR_NULL;
+    if (rows < 0 || E <= 0) return HPCS_ERR_SHAPE;
+    if (rows == 0) return HPCS_OK;
+    hipLaunchKernelGGL(hyp_lca_coord_bwd_kernel, ROW_GRID(rows), a, b, gcoord, rows, E, ga, gb);
     HPCS_CHECK_LAUNCH();
     return HPCS_OK;
 }

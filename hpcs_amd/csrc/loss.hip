@@ -745,7 +745,6 @@ __global__ __launch_bounds__(SB_THREADS) void hyphc_sampled_kernel(
             const int slot = rn + (rn >= c_off ? c_na : 0);
             in_own = order[slot < M ? slot : M - 1];
         }
-        if (a_dbg && lv_own) { a_dbg[tl] = ia_own; p_dbg[tl] = ip_own; n_dbg[tl] = in_own; }
         const int cpos_own = (c == cb && pr_own < RC) ? pr_own : -1;       // slot in the LDS positive table, or -1
 
         // ---- phase A: the group walks its 8 triplets for the three dot products; lane j keeps those of triplet j.
@@ -803,6 +802,8 @@ __global__ __launch_bounds__(SB_THREADS) void hyphc_sampled_kernel(
         bool live = lv_own;
         if (kind >= 0) live = live && keep_rule(0.5f * (1.f + D1) - 0.5f * (1.f + D2), margin, kind);
         if (live) ++kept;
+        // debug export (tests): the sampled triplet; a triplet the miner's rule dropped carries ~anchor (negative)
+        if (a_dbg && lv_own) { a_dbg[tl] = live ? ia_own : ~ia_own; p_dbg[tl] = ip_own; n_dbg[tl] = in_own; }
         const LcaF L1 = lca_of_dot(sc, D1), L2 = lca_of_dot(sc, D2), L3 = lca_of_dot(sc, D3);
         const float q0 = L1.d * inv_t, q1 = L2.d * inv_t, q2 = L3.d * inv_t;
         const float mx = fmaxf(q0, fmaxf(q1, q2));
@@ -1102,7 +1103,6 @@ __global__ __launch_bounds__(SB_THREADS) void hyphc_sampled4_kernel(
             const int slot = rn + (rn >= c_off ? c_na : 0);
             in_own = order[slot < M ? slot : M - 1];
         }
-        if (a_dbg && lv_own && owner) { a_dbg[tl] = ia_own; p_dbg[tl] = ip_own; n_dbg[tl] = in_own; }
         const int cpos_own = (c == cb && pr_own < RC) ? pr_own : -1;       // slot in the LDS positive table, or -1
 
         // ---- phase A: all eight rows of the batch in flight at once; three dot products per triplet
@@ -1153,6 +1153,8 @@ __global__ __launch_bounds__(SB_THREADS) void hyphc_sampled4_kernel(
         bool live = lv_own;
         if (kind >= 0) live = live && keep_rule(0.5f * (1.f + D1) - 0.5f * (1.f + D2), margin, kind);
         if (live && owner) ++kept;
+        // debug export (tests): the sampled triplet; a triplet the miner's rule dropped carries ~anchor (negative)
+        if (a_dbg && lv_own && owner) { a_dbg[tl] = live ? ia_own : ~ia_own; p_dbg[tl] = ip_own; n_dbg[tl] = in_own; }
         // Lanes s and s + 4 hold the same triplet: the lower quad evaluates the (a, p) distance, the upper quad the (p, n)
         // distance, then they swap -- two LCA evaluations per lane instead of three.
         LcaF L1, L3;
@@ -2081,13 +2083,31 @@ extern "C" int hpcs_hyphc_sampled(const float* xn, const int64_t* labels, const 
     // one 1024-thread workgroup per CU (forcing 8 waves/SIMD spills: measured 2.4x slower)
     // 156 of the CU's 160 KB (gfx950): 731 table rows at E = 32 instead of 556 at the 128 KB this was sized for -- fewer positives
     // take the global-atomic route (-1.2 % kernel time on the bench's imbalanced labels)
-    static const size_t lds_budget = [] { const char* e = getenv("HPCS_SAMPLED_LDS_KB"); return (size_t)(e ? atoi(e) : 156) * 1024; }();
-    int RC = grad ? (int)((lds_budget - slab_bytes) / ((E + 8) * sizeof(float))) : 0;     // rows of the positive table
-    if (RC > 1024) RC = 1024;
-    const size_t lds = (size_t)RC * (E + 8) * sizeof(float) + slab_bytes;
+    // The budget is clamped to what the device offers per workgroup (queried once; gfx950: 160 KB) minus the kernel's static
+    // LDS, and to at least the rings plus one table row (HPCS_SAMPLED_LDS_KB was used unchecked).
+    static const size_t lds_budget = [] {
+        int dev = 0, cap = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cap, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || cap <= 0)
+            cap = 64 * 1024;
+        const size_t room = (size_t)cap > 4096 ? (size_t)cap - 4096 : (size_t)cap;      // static LDS of the kernel + slack
+        const char* e = getenv("HPCS_SAMPLED_LDS_KB");
+        size_t want = (size_t)((e && atoi(e) > 0) ? atoi(e) : 156) * 1024;
+        return want < room ? want : room;
+    }();
+    const size_t row_bytes = (size_t)(E + 8) * sizeof(float);
+    int RC = 0;                                                                          // rows of the positive table
+    if (grad) {
+        RC = lds_budget > slab_bytes + row_bytes ? (int)((lds_budget - slab_bytes) / row_bytes) : 1;
+        if (RC > 1024) RC = 1024;
+    }
+    const size_t lds = (size_t)RC * row_bytes + slab_bytes;
 #define HPCS_SAMPLED_LAUNCH(KERNEL, EPL)                                                                              \
         if (grad) {                                                                                                   \
-            (void)hipFuncSetAttribute((const void*)KERNEL<EPL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (hipFuncSetAttribute((const void*)KERNEL<EPL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
+                (void)hipGetLastError();                                                                              \
+                return HPCS_ERR_UNSUPPORTED;                                                                          \
+            }                                                                                                         \
             hipLaunchKernelGGL((KERNEL<EPL, true>), grid, dim3(SB_THREADS), lds, ST, xn, labels, order,               \
                                offsets, cls_toff, cls_k, C, M, T, seed, seed_dev, scale, temperature, margin, kind, RC, loss_sum, \
                                (unsigned long long*)kept, gxn, gscale, a_dbg, p_dbg, n_dbg, perm_mul, seg_len);                \

@@ -100,6 +100,11 @@ class HypHCFn(torch.autograd.Function):
         return gxn, gscale, None, None, None, None, None, None, None
 
 
+def sampled_width(E):
+    """Row width hpcs_hyphc_sampled runs an embedding size on (16 / 32 / 64), or None beyond 64."""
+    return 16 if E <= 16 else 32 if E <= 32 else 64 if E <= 64 else None
+
+
 class HypHCSampledFn(torch.autograd.Function):
     """HypHC term with the class-balanced triplets generated INSIDE the kernel (device RNG): no index arrays, no
     sampler / filter passes; loss, kept count and unscaled gradient in one sweep (hpcs_hyphc_sampled)."""
@@ -108,9 +113,17 @@ class HypHCSampledFn(torch.autograd.Function):
     def forward(ctx, xn, scale, labels, order, offsets, toff, kk, T, seed, temperature, margin, kind, debug, seed_dev=None):
         """T sizes the grid (>= toff[C], the count the kernel reads on the device); seed_dev (int64[1] device tensor)
         overrides the by-value seed -- both so that a captured launch can be replayed with per-step values."""
-        M, E = xn.shape
+        M, E_in = xn.shape
         dev = xn.device
         C = kk.numel()
+        # The kernel gathers rows as 16-byte pieces, 8 lanes per row: widths 16 / 32 / 64.  Any other embedding size (the
+        # reference shipped 50, 4 and 15: checkpoints/*/config.yaml) runs on a zero-padded copy -- zero columns change no dot
+        # product and their gradient is exactly zero; backward returns the first E_in columns.
+        E = sampled_width(E_in)
+        if E != E_in:
+            xk = torch.zeros(M, E, device=dev)
+            xk[:, :E_in] = xn
+            xn = xk
         loss_sum = torch.empty(1, dtype=torch.float64, device=dev)
         kept = torch.empty(1, dtype=torch.int64, device=dev)
         need_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
@@ -119,10 +132,14 @@ class HypHCSampledFn(torch.autograd.Function):
         dbg = [None, None, None]
         if debug is not None:
             dbg = [torch.zeros(T, dtype=torch.int64, device=dev) for _ in range(3)]
-            debug.extend(dbg)
         call("hpcs_hyphc_sampled", xn, labels, order, offsets, toff, kk, C, M, E, T, int(seed) & (2 ** 63 - 1), seed_dev,
              scale, temperature, margin, _KIND[kind], loss_sum, kept, gxn_raw, gscale_raw, dbg[0], dbg[1], dbg[2])
+        if debug is not None:
+            # (a, p, n, kept): a triplet the miner's rule dropped is exported with ~anchor (negative)
+            live = dbg[0] >= 0
+            debug.extend([torch.where(live, dbg[0], -1 - dbg[0]), dbg[1], dbg[2], live])
         _LAST_KEPT[0] = kept
+        ctx.E_in = E_in
         colsum = torch.empty(E, dtype=torch.float64, device=dev)
         call("hpcs_colsum", xn, M, E, colsum)
         out = torch.empty(1, dtype=torch.float32, device=dev)
@@ -141,6 +158,8 @@ class HypHCSampledFn(torch.autograd.Function):
         gscale = torch.empty(1, dtype=torch.float32, device=gxn_raw.device)
         # in place on the kernel's unscaled gradient (a saved tensor nobody reads again): one launch
         call("hpcs_hyphc_grad_finalize", g32, kept, colsum, gscale_raw, M, gxn_raw.shape[1], gxn_raw, gscale)
+        if ctx.E_in != gxn_raw.shape[1]:
+            gxn_raw = gxn_raw[:, :ctx.E_in].contiguous()
         return (gxn_raw, gscale.view_as(scale)) + (None,) * 12
 
 
@@ -318,7 +337,7 @@ class MetricHyperbolicLoss(torch.nn.Module):
                     plan = TripletPlan.from_labels(labels, m.t_per_anchor, m.fraction)
                 from_ctx = step_ctx is not None and step_ctx.plan is plan and step_ctx.miner_seed is not None
                 seed = step_ctx.miner_seed if from_ctx else m.next_seed()
-                if m.rng == "device" and xn.shape[1] in (16, 32, 64) and plan.T > 0:
+                if m.rng == "device" and sampled_width(xn.shape[1]) is not None and plan.T > 0:
                     # device RNG: triplets are generated inside the loss kernel (no index arrays at all)
                     lab = labels.reshape(-1).to(torch.int64).contiguous()
                     order, offsets = class_index(lab, plan.C)

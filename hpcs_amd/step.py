@@ -26,15 +26,29 @@ def _gc_settle():
     40-100 ms measured) and lands within the first ~50 steps of a loop -- a host stall of 4-9 step times with the GPU idle
     (r03: it was the 10.9 ... 16 ms run-to-run spread of 20-step measurements).  Freezing moves the objects alive now into
     the permanent generation: later full collections only walk what training allocated since.  Collection itself stays on.
-    HPCS_GC_FREEZE=0 leaves the collector alone."""
+    OPT-IN (a library must not freeze the embedding application's heap behind its back): HPCS_GC_FREEZE=1, which
+    bench.py sets for its own process; INTEGRATION.md tells a training script how to do the same."""
     global _GC_SETTLED
     if _GC_SETTLED:
         return
     _GC_SETTLED = True
-    if __import__("os").environ.get("HPCS_GC_FREEZE", "1") != "0":
+    if __import__("os").environ.get("HPCS_GC_FREEZE", "0") == "1":
         import gc
         gc.collect()
         gc.freeze()
+
+
+def _new_graph():
+    """A CUDAGraph that keeps its hipGraph_t so that the capture can be inspected (torch >= 2.8: keep_graph)."""
+    try:
+        return torch.cuda.CUDAGraph(keep_graph=True), True
+    except TypeError:
+        return torch.cuda.CUDAGraph(), False
+
+
+def _lib_graph_census(graph):
+    from . import _lib
+    return _lib.graph_census(graph)
 
 
 def _watch_disarm(freeze=False):
@@ -136,6 +150,8 @@ class HypHCStep(torch.nn.Module):
         self.bucket = None
         self.params_block = None
         self.num_class = num_class
+        self.poisoned = False               # True: a step raised after its optimiser launch (see _rewind_or_poison)
+        self.last_capture_nodes = None      # node census of the last hipGraph capture ({"fwd_bwd": {...}, "opt": {...}})
 
     def configure(self):
         """Call once the module is on its device: flat gradient bucket + RAdam over ALL parameters (base_hyp_hc.py:143)
@@ -443,19 +459,31 @@ class HypHCStep(torch.nn.Module):
 
     def _eager_step(self, points, label, targets, targets_host, rot=None, drop_masks=None):
         saved = self._counters()
+        self._committed = False
         try:
             ctx = self._prepare(targets_host, own_rotation=(self.train_rotation == "so3" and rot is None),
                                 own_dropout=drop_masks is None)
             return self._run_eager(points, label, targets, ctx, rot, drop_masks)
         except BaseException:
-            # RAdam's bias-correction count, the miner / rotation / dropout streams were advanced for a step that never
-            # applied (a caught OOM, a label check, a skipped batch): the reference only advances them inside a step that ran
-            self._restore_counters(saved)
+            self._rewind_or_poison(saved)
             raise
+
+    def _rewind_or_poison(self, saved):
+        """A step that raised BEFORE its optimiser launch left the device-side training state (weights, moments) untouched:
+        RAdam's bias-correction count and the miner / rotation / dropout streams -- advanced on the host while the step was
+        prepared -- are rewound, as the reference only advances them inside a step that ran (a caught OOM, a label check, a
+        skipped batch).  Once the optimiser (or the replay that contains it) has been enqueued the device state HAS moved:
+        rewinding the host counters then would desynchronise bias correction and the RNG streams from it, so
+        they are kept and the step object is marked (`poisoned`: the failure is the caller's to handle)."""
+        if getattr(self, "_committed", False):
+            self.poisoned = True
+        else:
+            self._restore_counters(saved)
 
     def _run_eager(self, points, label, targets, ctx, rot=None, drop_masks=None):
         losses = self._backward_part(points, label, targets, ctx, rot, drop_masks)
         self.bucket.all_reduce_mean()
+        self._committed = True                 # from here on the device-side weights / moments move
         self.optimizer.step(tables=ctx.radam_tables, tables_dev=ctx.radam_dev)
         _watch_disarm()
         return losses
@@ -470,23 +498,38 @@ class HypHCStep(torch.nn.Module):
         side = self.side_stream_wgrad
         self.side_stream_wgrad = side and self._graph_form == "side"
         try:
-            g["fwd_bwd"] = torch.cuda.CUDAGraph()
+            g["fwd_bwd"], kept_raw = _new_graph()
             with torch.cuda.graph(g["fwd_bwd"], capture_error_mode="thread_local"):
                 g["out"] = self._backward_part(*g["in"], ctx, None, None)
                 if world == 1:
                     self.optimizer.step(tables=ctx.radam_tables, tables_dev=ctx.radam_dev)
             if world > 1:
                 g["pool"] = g["fwd_bwd"].pool()
-                g["opt"] = torch.cuda.CUDAGraph()
+                g["opt"], _ = _new_graph()
                 with torch.cuda.graph(g["opt"], pool=g["pool"], capture_error_mode="thread_local"):
                     self.optimizer.step(tables=ctx.radam_tables, tables_dev=ctx.radam_dev)
         finally:
             self.side_stream_wgrad = side
             _watch_disarm(freeze=True)
+        # the source scan over csrc/ cannot see what torch's own ops put into the capture.  Walk the captured
+        # graph(s): a memset NODE (hipMemsetAsync -- a torch fill of some shapes, the semaphores of a multi-block
+        # reduction) loses its arguments once a second graph is instantiated on this runtime, so such a
+        # capture is refused and the step stays eager.  memcpy nodes replay correctly (same reproducer) and are reported.
+        g["nodes"] = {}
+        for key in ("fwd_bwd", "opt"):
+            if key in g:
+                census = _lib_graph_census(g[key]) if kept_raw else None
+                g["nodes"][key] = census
+                if census is not None and census.get("memset", 0):
+                    raise RuntimeError(f"the captured step holds {census['memset']} memset node(s) ({census}): refused")
+                if kept_raw:
+                    g[key].instantiate()           # keep_graph defers instantiation to here (after the inspection)
+        self.last_capture_nodes = g["nodes"]
         return g
 
     def _graphed_step(self, points, label, targets, targets_host):
         saved = self._counters()
+        self._committed = False
         try:
             g = self._graph
             shapes = (tuple(points.shape), tuple(label.shape), tuple(targets.shape), points.dtype, label.dtype, targets.dtype)
@@ -523,6 +566,7 @@ class HypHCStep(torch.nn.Module):
             for dst, src in zip(g["in"], (points, label, targets)):
                 if dst.data_ptr() != src.data_ptr():
                     dst.copy_(src, non_blocking=True)
+            self._committed = True             # the replay contains the optimiser (world 1) / is followed by it
             g["fwd_bwd"].replay()
             if g["world"] > 1:
                 self.bucket.all_reduce_mean()
@@ -530,5 +574,5 @@ class HypHCStep(torch.nn.Module):
             self.metric_hyp_loss.last_T = ctx.plan.T
             return g["out"]
         except BaseException:
-            self._restore_counters(saved)
+            self._rewind_or_poison(saved)
             raise

@@ -281,6 +281,10 @@ int hpcs_hyp_lca_fwd(const float* a, const float* b, int64_t rows, int E, float*
                      hpcs_stream_t stream);
 int hpcs_hyp_lca_bwd(const float* a, const float* b, const float* gdist, int64_t rows, int E, float* ga, float* gb,
                      hpcs_stream_t stream);
+/* backward of the coordinate output (return_coord=True is differentiable in the reference, hpcs/distances/lca.py:37-52):
+ * gcoord [rows,E] = dL/dproj -> ga, gb [rows,E] */
+int hpcs_hyp_lca_coord_bwd(const float* a, const float* b, const float* gcoord, int64_t rows, int E, float* ga, float* gb,
+                           hpcs_stream_t stream);
 /* a15: HyperbolicDistance.compute_mat  hpcs/distances/poincare.py:144-176 -> sim [M,M'] */
 int hpcs_hyperbolic_sim_mat(const float* x, const float* y, int M, int Mp, int E, float* out, hpcs_stream_t stream);
 /* a15: HyperbolicDistance.pairwise_distance  hpcs/distances/poincare.py:178-187 -> sim [M] of the row-aligned pairs */
@@ -344,7 +348,9 @@ int hpcs_hyphc_bwd(const float* xn, int E, const int64_t* a, const int64_t* p, c
  * (class index, per-class plan, seed) -- no index arrays, no sampler/filter pass -- the margin rule `kind` is applied
  * inline, and loss_sum[1], kept[1] and (gxn != NULL) the UNSCALED gradient gxn [M,E] (zero-filled by the call's own
  * zero launch, then accumulated into) + gscale[1] come out of one sweep.  Positive-row gradients are accumulated in an LDS table per
- * workgroup.  E must be 16, 32 or 64.  a_dbg/p_dbg/n_dbg (nullable, [T]) receive the generated triplets (tests).
+ * workgroup.  E must be 16, 32 or 64 (the host mirror zero-pads other widths up to the next of these: zero columns change
+ * no dot product and receive zero gradient).  a_dbg/p_dbg/n_dbg (nullable, [T]) receive the generated triplets (tests);
+ * a triplet the miner's rule dropped is exported with a_dbg = ~anchor (negative).
  * T sizes the grid only and must be >= cls_toff[C], the number of triplets the kernel actually samples (read on the
  * device): a captured launch sized for the largest batch serves smaller ones, surplus workgroups exit at once. */
 int hpcs_hyphc_sampled(const float* xn, const int64_t* labels, const int32_t* order, const int32_t* offsets,
@@ -453,6 +459,10 @@ int hpcs_zero_buffers(void* p0, size_t n0, void* p1, size_t n1, void* p2, size_t
 int hpcs_debug_snapshot(const void* src, void* dst, int nbytes, hpcs_stream_t stream);
 int hpcs_debug_watch(const void* watched, const void* shadow, int nbytes, int seq, int32_t* status,
                      hpcs_stream_t stream);
+/* Node census of a captured hipGraph (host-only): counts16[t] = nodes of hipGraphNodeType t (0 kernel, 1 memcpy, 2 memset,
+ * 3 host, 4 child graph, 5 empty, ...), child graphs included.  Returns the node total or a negative status.  The step
+ * driver refuses a capture holding memset nodes (their arguments do not survive a second graph on this runtime). */
+int hpcs_debug_graph_census(void* graph, int64_t* counts16);
 
 #ifdef __cplusplus
 }

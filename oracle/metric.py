@@ -159,12 +159,9 @@ def scale_to_diameter(x, scale):
     return F.normalize(x, p=2, dim=1) * torch.clamp(scale, 1e-4, 1)
 
 
-def hyphc_loss(x_poincare, triplets, scale, temperature, mat_mean="matrix"):
-    """compute_hyp given already mined triplets.
-
-    mat_mean="matrix": mean of the materialised M x M similarity (the reference);
-    mat_mean="closed": 0.5 + 0.5*|sum_i x_hat_i|^2 / M^2 (what the HIP path computes).
-    """
+def hyphc_terms(x_poincare, triplets, scale, temperature):
+    """The per-triplet summand of compute_hyp (ultrametric_loss.py:65-91): sum(w) - sum(w * softmax(d_lca / temperature)),
+    [T]; similarities as row dots of the normalised rows (= the entries the reference gathers from its M x M matrix)."""
     a, p, n = triplets
     xn = l2_rows(x_poincare)
     wij = 0.5 * (1 + (xn[a] * xn[p]).sum(1))
@@ -176,7 +173,17 @@ def hyphc_loss(x_poincare, triplets, scale, temperature, mat_mean="matrix"):
     d = torch.cat([H.hyp_lca(e1, e2, False), H.hyp_lca(e1, e3, False), H.hyp_lca(e2, e3, False)], dim=1)  # [T,3]
     w = torch.stack([wij, wik, wjk], dim=1)                                                               # [T,3]
     soft = torch.softmax(d / temperature, dim=-1)
-    per_triplet = w.sum(-1) - (w * soft).sum(-1)
+    return w.sum(-1) - (w * soft).sum(-1)
+
+
+def hyphc_loss(x_poincare, triplets, scale, temperature, mat_mean="matrix"):
+    """compute_hyp given already mined triplets.
+
+    mat_mean="matrix": mean of the materialised M x M similarity (the reference);
+    mat_mean="closed": 0.5 + 0.5*|sum_i x_hat_i|^2 / M^2 (what the HIP path computes).
+    """
+    per_triplet = hyphc_terms(x_poincare, triplets, scale, temperature)
+    xn = l2_rows(x_poincare)
     if mat_mean == "matrix":
         mm = cosine_sim_mat(x_poincare).mean()
     else:

@@ -152,3 +152,23 @@ def test_hyphc_step_world2_matches_serial_mean_gradient(tmp_path):
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
     json.dump({"rank0": r0, "rank1": r1}, open(os.path.join(out, "dp_world2_r03.json"), "w"), indent=1)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher environment must start its ranks itself (fresh child
+    processes; both share cuda:0 here, gloo as the collective), relay rank 0's JSON line and exit 0."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HPCS_SINGLE_DEVICE_REHEARSAL="1", HPCS_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["config"]["global_batch"] == 64
+    dp = out["config"]["data_parallel"]
+    assert dp and len(dp["per_rank_ms_per_step"]) == 2 and dp["allreduce_bytes"] > 5_000_000
+    assert out["value"] > 0 and out["scaling"] == "weak"
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "bench_selflaunch_world2.json"), "w"), indent=1)

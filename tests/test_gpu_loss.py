@@ -252,7 +252,7 @@ def test_hyphc_sampled_in_kernel(variant, E, monkeypatch):
     xg = x.to(dev).requires_grad_(True)
     lh = crit.compute_hyp(xg, lab.to(dev))
     lh.backward()
-    a, p, n = crit.debug_triplets
+    a, p, n, _live = crit.debug_triplets
     T = a.numel()
     plan = crit.make_plan(lab)
     assert T == plan.T == crit.last_T

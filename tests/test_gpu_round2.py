@@ -347,7 +347,7 @@ def test_successive_steps_draw_different_triplets():
             crit.debug_triplets = []
             with torch.no_grad():
                 crit.compute_hyp(x, lab)
-            out.append([t.cpu() for t in crit.debug_triplets])
+            out.append([t.cpu() for t in crit.debug_triplets[:3]])
         return out
     torch.manual_seed(123)
     s1 = draws(3)
@@ -386,7 +386,7 @@ def test_negative_sampling_is_exact_for_a_dominant_class():
     crit.debug_triplets = []
     with torch.no_grad():
         crit.compute_hyp(x, lab.to(dev))
-    a, p, n = [t.cpu() for t in crit.debug_triplets]
+    a, p, n = [t.cpu() for t in crit.debug_triplets[:3]]
     assert bool((lab[a] != lab[n]).all())
     big = lab[a] == 0
     hist = torch.bincount(n[big], minlength=M)[lab == 1].float()     # 164 candidates, ~196 draws each

@@ -1,0 +1,341 @@
+"""Round 4 GPU parity tests.
+
+1. The kernel the benchmark runs for rows a10 + a12 -- hpcs_hyphc_sampled: class-balanced triplets generated in-kernel,
+   the miner's margin rule inline, HypHC loss + gradient in one sweep -- DIRECTLY against the fp64 oracle
+   (oracle/metric.py: ultrametric_loss.py:57-93, triplet_margin_miner.py:13-38, loss_and_miner_utils.py:33-61 restated),
+   not through another HIP kernel: kept set (tie-aware), loss, gradients, and the distribution of the sampled triplets.
+2. The embedding sizes the reference shipped (checkpoints/*/config.yaml: 50, 4, 15) on every loss path.
+3. BASELINE configs[1] (B = 32, N = 1024, k = 20, C = 50, 16 categories, flat CosFace) as one full step.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from _det import det_cloud, det_int, det_normalish, det_params
+from oracle import extractor as OE, hyperbolic as OH, metric as OM
+
+pytestmark = pytest.mark.gpu
+dev = "cuda"
+
+
+def relerr(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-300))
+
+
+def bench_labels():
+    """The benchmark's part labels: Voronoi cells of 50 centroids over 32 clouds of 1024 points (imbalanced on purpose)."""
+    import bench
+    return bench.synthetic_batch(32, 1024, 50, 16, seed=0)[2].reshape(-1)
+
+
+def one_big_class(M, C, big, seed):
+    return torch.cat([det_int((M - big,), seed, C - 1), torch.full((big,), C - 1)])
+
+
+def oracle_hyphc(x, kept, scale, temperature, device, chunk=1 << 20):
+    """OM.hyphc_loss (fp64, closed-form matrix mean) and its gradients with respect to x and scale, the triplet sum taken in
+    chunks.  device="cuda": the oracle's torch code evaluated by torch in fp64 on the device (torch's own kernels, none of
+    the library's), for triplet counts the host would need minutes for."""
+    x64 = x.detach().to(device=device, dtype=torch.float64).requires_grad_(True)
+    s64 = torch.tensor([float(scale)], dtype=torch.float64, device=device, requires_grad=True)
+    a, p, n = (t.to(device) for t in kept)
+    K = a.numel()
+    total = 0.0
+    for i in range(0, K, chunk):
+        part = OM.hyphc_terms(x64, (a[i:i + chunk], p[i:i + chunk], n[i:i + chunk]), s64, temperature).sum() / K
+        part.backward()
+        total += float(part)
+    M = x64.shape[0]
+    xn = OM.l2_rows(x64)
+    sm = xn.sum(0)
+    mm = 0.5 + 0.5 * (sm * sm).sum() / (M * M)
+    mm.backward()
+    return total + float(mm), x64.grad.cpu(), float(s64.grad)
+
+
+def chi2_band(stat, dof, sigmas=6.0):
+    return abs(stat - dof) <= sigmas * math.sqrt(2.0 * dof)
+
+
+def check_sampled_against_oracle(E, M, lab, t_per_anchor, scale, oracle_device, gathered32, variant=None, monkeypatch=None,
+                                 chi2=False):
+    from hpcs_amd.loss.ultrametric_loss import MetricHyperbolicLoss
+    if variant is not None:
+        monkeypatch.setenv("HPCS_SAMPLED_V", variant)
+    C = int(lab.max()) + 1
+    x = OH.expmap0(det_normalish((M, E), 61 + E) * 0.5)
+    crit = MetricHyperbolicLoss(t_per_anchor=t_per_anchor, fraction=1.2, scale=torch.nn.Parameter(torch.tensor([scale])),
+                                temperature=0.05, num_class=C, embedding_size=E, cosface=True, miner=True, rng="device",
+                                fused_filter=True).to(dev)
+    crit.debug_triplets = []
+    xg = x.to(dev).requires_grad_(True)
+    lh = crit.compute_hyp(xg, lab.to(dev))
+    lh.backward()
+    a, p, n, live = crit.debug_triplets
+    T = a.numel()
+    plan = crit.make_plan(lab)
+    assert T == plan.T == crit.last_T
+    assert int(live.sum()) == int(crit.last_kept)                         # the exported flags are the kernel's kept count
+    # ---- validity of the sampled triplets (loss_and_miner_utils.py:33-61: same class, not the anchor; another class)
+    lab_d = lab.to(dev)
+    assert bool((lab_d[a] == lab_d[p]).all()) and bool((a != p).all()) and bool((lab_d[a] != lab_d[n]).all())
+    assert bool((torch.bincount(a, minlength=M).cpu() == plan.k[lab].long()).all())      # every anchor exactly k_l times
+    # ---- (i) the miner's rule (triplet_margin_miner.py:20-30, 'easy', margin 0) in fp64 on the normalised rows
+    xn64 = F.normalize(x.double(), dim=1).to(dev)
+    tm = 0.5 * ((xn64[a] * xn64[p]).sum(1) - (xn64[a] * xn64[n]).sum(1))
+    odd = (tm > 0) != live
+    assert int(odd.sum()) <= max(8, T // 20000), int(odd.sum())
+    assert float(tm[odd].abs().max()) <= 2e-6 if bool(odd.any()) else True
+    # ---- (ii) + (iii) loss and gradients on the triplets the kernel kept, fp64 oracle
+    kept = (a[live], p[live], n[live])
+    want, gx64, gs64 = oracle_hyphc(x, kept, scale, 0.05, oracle_device)
+    assert abs(float(lh) - want) <= 2e-6 * abs(want), (float(lh), want)
+    e_gx = relerr(xg.grad, gx64)
+    assert e_gx <= 2e-4, e_gx
+    assert abs(float(crit.scale.grad) - gs64) <= 1e-3 * abs(gs64) + 1e-12, (float(crit.scale.grad), gs64)
+    if oracle_device != "cpu":
+        # anchor torch-on-the-device to torch-on-the-host: the same oracle terms on a 200 k subsample, both in fp64
+        sel = torch.arange(0, kept[0].numel(), max(1, kept[0].numel() // 200000), device=dev)
+        sub = tuple(t[sel] for t in kept)
+        s64 = torch.tensor([scale], dtype=torch.float64)
+        t_dev = OM.hyphc_terms(x.double().to(dev), sub, s64.to(dev), 0.05).cpu()
+        t_cpu = OM.hyphc_terms(x.double(), tuple(t.cpu() for t in sub), s64, 0.05)
+        assert float((t_dev - t_cpu).abs().max()) <= 1e-12
+    if gathered32:
+        # the reference's own op order in fp32: M x M matrix, gathers, reflections (ultrametric_loss.py:57-93 as written)
+        lh32 = OM.hyphc_loss_gathered(x, tuple(t.cpu() for t in kept), torch.tensor([scale]), 0.05)
+        assert abs(float(lh) - float(lh32)) <= 1e-5 * abs(float(lh32)), (float(lh), float(lh32))
+    # ---- the gradient-free instantiation on the same stream
+    crit.debug_triplets = None
+    crit.hyp_miner.seed -= 1
+    with torch.no_grad():
+        l3 = crit.compute_hyp(x.to(dev), lab_d)
+    assert abs(float(l3) - want) <= 2e-6 * abs(want)
+    if chi2:
+        # positives: uniform over the anchor's class minus the anchor => every member of a class is drawn k_l times on
+        # average as a positive; negatives: uniform over the other classes' points (loss_and_miner_utils.py:43-62)
+        counts = torch.bincount(lab, minlength=C).double()
+        kk = plan.k.double()
+        pos_hist = torch.bincount(p, minlength=M).cpu().double()
+        exp_pos = kk[lab]
+        ok = exp_pos > 0
+        stat = float((((pos_hist - exp_pos) ** 2)[ok] / exp_pos[ok]).sum())
+        assert chi2_band(stat, int(ok.sum()) - int((counts > 1).sum())), ("positives", stat, int(ok.sum()))
+        t_c = counts * kk                                                 # triplets per anchor class
+        share = t_c / (M - counts)                                       # expected draws per outside point, per class
+        exp_neg = share.sum() - share[lab]
+        neg_hist = torch.bincount(n, minlength=M).cpu().double()
+        stat = float((((neg_hist - exp_neg) ** 2) / exp_neg).sum())
+        assert chi2_band(stat, M - C), ("negatives", stat, M)
+        # and per anchor class the negatives are spread over the other classes in proportion to their sizes
+        big = int(counts.argmax())
+        from_big = n[lab_d[a] == big]
+        hist_c = torch.bincount(lab_d[from_big], minlength=C).cpu().double()
+        assert float(hist_c[big]) == 0.0
+        exp_c = counts * from_big.numel() / (M - counts[big])
+        exp_c[big] = 0.0
+        okc = exp_c > 0
+        stat = float((((hist_c - exp_c) ** 2)[okc] / exp_c[okc]).sum())
+        assert chi2_band(stat, int(okc.sum()) - 1), ("negatives by class", stat)
+    return {"T": T, "kept": int(live.sum()), "near_tie_flips": int(odd.sum()), "loss_rel": abs(float(lh) - want) / abs(want),
+            "grad_l2": e_gx}
+
+
+@pytest.mark.parametrize("variant,E,scale", [("4", 32, 0.03), ("4", 32, 1e-3), ("8", 32, 0.03), ("4", 16, 0.03), ("4", 64, 0.03)])
+def test_sampled_hyphc_kernel_against_the_fp64_oracle(variant, E, scale, monkeypatch):
+    """M = 6000 with one class of 1500 rows (beyond the LDS positive table at every E: overflow rows and finished anchors
+    leave through the ring), oracle on the host."""
+    lab = one_big_class(6000, 7, 1500, 62)
+    check_sampled_against_oracle(E, 6000, lab, 9, scale, "cpu", gathered32=True, variant=variant, monkeypatch=monkeypatch,
+                                 chi2=(variant == "4" and E == 32 and scale == 0.03))
+
+
+@pytest.mark.parametrize("variant", ["4", "8"])
+def test_sampled_hyphc_kernel_at_the_bench_size(variant, monkeypatch):
+    """The benchmark's own loss workload: M = 32768, the Voronoi labels of bench.synthetic_batch (C = 50, four classes of
+    2600-3800 points), t_per_anchor = 50, fraction 1.2 -> 16.9 M sampled triplets; scale 1e-3 (base_hyp_hc.py:62)."""
+    lab = bench_labels()
+    r = check_sampled_against_oracle(32, 32768, lab, 50, 1e-3, dev, gathered32=False, variant=variant,
+                                     monkeypatch=monkeypatch, chi2=(variant == "4"))
+    assert r["T"] > 16_000_000
+
+
+@pytest.mark.parametrize("E", [4, 15, 50])
+def test_sampled_hyphc_kernel_at_the_shipped_embedding_sizes(E):
+    """checkpoints/shapenet/config.yaml:65-67 (E = 50), checkpoints/partnet/*/config.yaml (4; Bed 15): the device-RNG path
+    runs these on zero-padded rows (ultrametric_loss.sampled_width)."""
+    lab = one_big_class(6000, 7, 1500, 62)
+    check_sampled_against_oracle(E, 6000, lab, 9, 0.03, "cpu", gathered32=True)
+
+
+@pytest.mark.parametrize("E", [4, 15, 50])
+def test_array_path_losses_at_the_shipped_embedding_sizes(E):
+    """Host-RNG miner -> HypHC + CosFace, and the triplet-margin branch, at E = 4 / 15 / 50 against the fp64 oracle
+    (values and gradients), like test_gpu_loss.py does at 32 / 16."""
+    from hpcs_amd.loss.ultrametric_loss import MetricHyperbolicLoss
+    M, C = 2000, 6
+    x = OH.expmap0(det_normalish((M, E), 11 + E) * 0.5)
+    lab = det_int((M,), 12, C)
+    s = 0.02
+    crit = MetricHyperbolicLoss(margin=0.35, t_per_anchor=10, fraction=1.2, scale=torch.nn.Parameter(torch.tensor([s])),
+                                temperature=0.05, num_class=C, embedding_size=E, cosface=True, miner=True).to(dev)
+    W = det_normalish((E, C), 13)
+    crit.loss_cosface.W.data.copy_(W)
+    xg = x.to(dev).requires_grad_(True)
+    torch.manual_seed(5)
+    out = crit.compute_loss(None, xg, lab.to(dev))
+    lh, lm = out["loss_hyp"]["losses"], out["loss_metric"]["losses"]
+    a, p, n, count = crit.last_triplets
+    c = int(count)
+    trip = (a[:c].cpu(), p[:c].cpu(), n[:c].cpu())
+    torch.manual_seed(5)
+    wa, wp, wn = OM.mine_triplets(x, lab, 10, 1.2, 0, "easy")                # the oracle's miner under the same seed
+    assert abs(wa.numel() - c) <= 8
+    x64 = x.double().requires_grad_(True)
+    s64 = torch.tensor([s], dtype=torch.float64, requires_grad=True)
+    W64 = W.double().requires_grad_(True)
+    lh64 = OM.hyphc_loss(x64, trip, s64, 0.05, mat_mean="closed")
+    lm64 = OM.cosface_loss(x64, lab, W64, 0.35, 2.0)
+    assert abs(float(lh) - float(lh64)) <= 2e-6 * abs(float(lh64))
+    assert abs(float(lm) - float(lm64)) <= 1e-5 * abs(float(lm64))
+    lh32 = OM.hyphc_loss_gathered(x, trip, torch.tensor([s]), 0.05)
+    assert abs(float(lh) - float(lh32)) <= 1e-5 * abs(float(lh32))
+    (0.1 * lh + lm).backward()
+    (0.1 * lh64 + lm64).backward()
+    assert relerr(xg.grad, x64.grad) <= 2e-4
+    assert relerr(crit.loss_cosface.W.grad, W64.grad) <= 2e-4
+    assert abs(float(crit.scale.grad) - float(s64.grad)) <= 1e-3 * abs(float(s64.grad)) + 1e-9
+    # triplet-margin branch (cosface=False): semihard miner + TripletMarginLoss with AvgNonZeroReducer
+    crit2 = MetricHyperbolicLoss(margin=0.35, t_per_anchor=8, fraction=1.2, scale=torch.tensor([0.05], device=dev),
+                                 temperature=0.05, num_class=C, embedding_size=E, cosface=False, miner=True)
+    xg2 = x.to(dev).requires_grad_(True)
+    torch.manual_seed(9)
+    lm2 = crit2.compute_loss(None, xg2, lab.to(dev))["loss_metric"]["losses"]
+    torch.manual_seed(9)
+    OM.mine_triplets(x, lab, 8, 1.2, 0, "easy")
+    t2 = OM.mine_triplets(x, lab, 8, 1.2, 0.35, "semihard")
+    x64b = x.double().requires_grad_(True)
+    want = OM.triplet_margin_loss(x64b, t2, 0.35)
+    assert abs(float(lm2) - float(want)) <= 1e-4 * abs(float(want))
+    lm2.backward()
+    want.backward()
+    assert relerr(xg2.grad, x64b.grad) <= 2e-3
+
+
+@pytest.mark.parametrize("E", [15, 50])
+def test_extractor_head_at_the_shipped_embedding_sizes(E):
+    """VN_DGCNN_partseg(out_features = 15 / 50) against the oracle on the same kNN graphs (train mode, dropout masks),
+    forward and parameter gradients of the head."""
+    from hpcs_amd import ops
+    from hpcs_amd.nn.dgcnn import VN_DGCNN_partseg
+    B, N, k = 4, 256, 10
+    net = VN_DGCNN_partseg(3, E, k=k, dropout=0.0, pooling="mean", num_categories=16)
+    P = det_params(OE.param_shapes(E, 16), 5)
+    net.load_state_dict(P, strict=True)
+    net.to(dev).train()
+    x = det_cloud(B, N, 6)
+    lab = torch.eye(16)[det_int((B,), 7, 16)]
+    graphs, real_knn = [], ops.knn
+
+    def recording_knn(xx, kk):
+        idx_ = real_knn(xx, kk)
+        graphs.append(idx_.cpu())
+        return idx_
+    ops.knn = recording_knn
+    try:
+        y = net(x.to(dev), lab.to(dev))
+    finally:
+        ops.knn = real_knn
+    w = det_normalish((B, N, E), 9)
+    (y * w.to(dev)).sum().backward()
+    Po = OE.resolve_aliases({k_: v.clone().double() if v.is_floating_point() else v.clone() for k_, v in P.items()})
+    learn = ["conv11.weight", "conv10.weight", "bn10.weight", "bn10.bias"]
+    for k_ in learn:
+        Po[k_].requires_grad_(True)
+    it = iter(graphs)
+    want = OE.vn_dgcnn_partseg(x.double(), lab.double(), Po, k=k, training=True, knn_fn=lambda xx, kk: next(it))
+    assert y.shape == (B, N, E)
+    assert float((y.detach().cpu().double() - want).abs().max() / want.abs().max()) <= 1e-4
+    (want * w.double()).sum().backward()
+    got = dict(net.named_parameters())
+    for k_ in learn:
+        assert relerr(got[k_].grad, Po[k_].grad) <= 2e-3, k_
+
+
+def test_smoke_step_at_embedding_size_4():
+    """The driver's smoke() (one training step against the oracle: embeddings, kept set, both loss terms) at E = 4, the
+    size of the shipped PartNet checkpoints."""
+    import __graft_entry__ as ge
+    ge.smoke(E=4)
+
+
+def test_config2_full_size_step():
+    """BASELINE configs[1] as ONE full step under -m gpu: B = 32, N = 1024, k = 20, E = 32, C = 50, 16 categories, flat
+    CosFace, device RNG, SO(3), dropout, side-stream weight gradients, RAdam -- bench.build_step's exact construction.
+    Checked: finite losses / parameters over 3 steps; the CosFace term, accuracy and IoU against the fp64 oracle /
+    confusion matrix on the step's own embeddings; the HypHC term's kept count inside the plan; RAdam's projection;
+    reproducibility of the first step under the same seeds."""
+    import argparse
+    import bench
+    args = argparse.Namespace(batch=32, points=1024, k=20, embedding=32, num_class=50, num_categories=16, hierarchical=False)
+    pts, cat, tgt = bench.synthetic_batch(32, 1024, 50, 16, seed=0)
+    pts_d, cat_d, tgt_d = pts.to(dev), cat.to(dev), tgt.to(dev)
+    firsts = []
+    for _ in range(2):
+        step = bench.build_step(args, torch.device(dev))
+        step.use_graph = False
+        emb = []
+        hook = step.nn_feat.register_forward_hook(lambda m_, i_, o_: emb.append(o_.detach()))
+        W0 = step.metric_hyp_loss.loss_cosface.W.detach().cpu().clone()
+        out = step.training_step(pts_d, cat_d, tgt_d, targets_host=tgt)
+        hook.remove()
+        first = {k_: float(v) for k_, v in out.items()}
+        firsts.append(first)
+        assert all(math.isfinite(v) for v in first.values()), first
+        # CosFace (a14) + in-step metrics on the step's own embeddings: fp64 oracle on the host (M = 32768, C = 50)
+        xp = OH.expmap0(emb[0].cpu().double()).reshape(-1, 32)
+        lab = tgt.reshape(-1)
+        logits = OM.cosface_logits(xp, lab, W0.double(), 0.35, 2.0)
+        lm = F.cross_entropy(logits, lab, reduction="none").mean()
+        assert abs(first["loss_metric"] - float(lm)) <= 1e-5 * abs(float(lm)), (first["loss_metric"], float(lm))
+        pred = logits.argmax(1)
+        assert abs(first["acc"] - float((pred == lab).double().mean())) <= 2e-4            # fp32 / fp64 arg-max near-ties
+        plan = step.metric_hyp_loss.make_plan(lab)
+        assert 0 < int(step.metric_hyp_loss.last_kept) <= plan.T == step.metric_hyp_loss.last_T
+        for _s in range(2):
+            out = step.training_step(pts_d, cat_d, tgt_d, targets_host=tgt)
+        assert all(math.isfinite(float(v)) for v in out.values())
+        for p_ in step.parameters():
+            assert bool(torch.isfinite(p_).all())
+            rows = p_.detach().reshape(-1, p_.shape[-1] if p_.dim() else 1)
+            assert float(rows.norm(dim=1).max()) <= 1 - 4e-3 + 1e-5
+    assert abs(firsts[0]["loss_metric"] - firsts[1]["loss_metric"]) <= 1e-6 * abs(firsts[0]["loss_metric"])
+    assert abs(firsts[0]["loss_hyp"] - firsts[1]["loss_hyp"]) <= 1e-5 * abs(firsts[0]["loss_hyp"])
+
+
+@pytest.mark.parametrize("E,scale", [(2, 0.5), (6, 0.3), (32, 0.05)])
+def test_hyp_lca_coordinate_output_is_differentiable(E, scale):
+    """hyp_lca(a, b, return_coord=True) (hpcs/distances/lca.py:37-52) returns the projection point WITH its gradient, like
+    the reference's; forward and vector-Jacobian product against the oracle's reflections evaluated in fp64."""
+    from hpcs_amd.distances import hyp_lca
+    a = det_normalish((300, E), 9701) * scale / E ** 0.5
+    b = det_normalish((300, E), 9702) * scale / E ** 0.5
+    b[0] = a[0] * 0.5                                   # collinear with the origin: the geodesic is a diameter, proj = 0
+    w = det_normalish((300, E), 9703)
+    ag, bg = a.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    p = hyp_lca(ag, bg, return_coord=True)
+    assert p.requires_grad
+    (p * w.to(dev)).sum().backward()
+    a64, b64 = a.double().requires_grad_(True), b.double().requires_grad_(True)
+    live = torch.ones(300, 1, dtype=torch.float64)
+    live[0] = 0.0
+    p64 = OH.hyp_lca(a64, b64, True)
+    assert relerr(p[1:], p64[1:]) <= 2e-6 and float(p[0].abs().max()) <= 1e-6
+    (p64 * w.double() * live).sum().backward()
+    assert relerr(ag.grad[1:], a64.grad[1:]) <= 2e-5, relerr(ag.grad[1:], a64.grad[1:])
+    assert relerr(bg.grad[1:], b64.grad[1:]) <= 2e-5
+    assert bool(torch.isfinite(ag.grad).all()) and bool(torch.isfinite(bg.grad).all())

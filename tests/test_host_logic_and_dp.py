@@ -94,15 +94,20 @@ def test_bucket_guards_against_detached_grads():
         b.zero()
 
 
-def test_gc_settle_runs_once_and_honours_the_switch(monkeypatch):
-    """hpcs_amd/step.py::_gc_settle: one collection + gc.freeze() per process (HPCS_GC_FREEZE=0: nothing)."""
+def test_gc_settle_is_opt_in_and_runs_once(monkeypatch):
+    """hpcs_amd/step.py::_gc_settle: nothing unless HPCS_GC_FREEZE=1 (ADVICE r3: no hidden process-wide gc.freeze() from
+    library code; bench.py opts in for its own process); with it, one collection + gc.freeze() per process."""
     import gc
     from hpcs_amd import step as S
-    monkeypatch.setattr(S, "_GC_SETTLED", False)
-    monkeypatch.setenv("HPCS_GC_FREEZE", "0")
     before = gc.get_freeze_count()
-    S._gc_settle()
-    assert gc.get_freeze_count() == before and S._GC_SETTLED
+    for off in (None, "0"):
+        monkeypatch.setattr(S, "_GC_SETTLED", False)
+        if off is None:
+            monkeypatch.delenv("HPCS_GC_FREEZE", raising=False)
+        else:
+            monkeypatch.setenv("HPCS_GC_FREEZE", off)
+        S._gc_settle()
+        assert gc.get_freeze_count() == before and S._GC_SETTLED
     monkeypatch.setattr(S, "_GC_SETTLED", False)
     monkeypatch.setenv("HPCS_GC_FREEZE", "1")
     try:
@@ -113,3 +118,21 @@ def test_gc_settle_runs_once_and_honours_the_switch(monkeypatch):
         assert gc.get_freeze_count() == frozen
     finally:
         gc.unfreeze()
+
+
+def test_bench_launcher_starts_fresh_rank_processes_without_a_gpu():
+    """`python bench.py --gpus 2` with no launcher environment starts its own ranks (fresh children under
+    torch.distributed.run, never an exec) and relays their status.  Here there is no GPU: every rank must come up, join the
+    gloo group and then stop at bench.py's own "needs an MI355X" exit -- a non-zero status the parent passes on."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if torch.cuda.is_available():
+        pytest.skip("CPU-side launcher test (tests/test_gpu_dp.py runs the real thing on a GPU)")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "launching 2 ranks" in r.stderr
+    assert r.stderr.count("bench.py needs an MI355X") >= 1, r.stderr[-2000:]
