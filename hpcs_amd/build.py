@@ -25,8 +25,8 @@ def _stale(target, deps):
 
 def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    hdrs = [os.path.join(CSRC, "common.h"),
-            os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "hpcs_mi355x.h")]
+    hdrs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")] + \
+           [os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "hpcs_mi355x.h")]
     objs, jobs = [], []
     for src in _sources():
         s = os.path.join(CSRC, src)

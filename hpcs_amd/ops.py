@@ -16,6 +16,10 @@ FUSED_EDGE_BACKWARD = bool(__import__("os").environ.get("HPCS_FUSED_BWD"))
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 # conv1 (two input channels) forms its pre-activations inside the point-wise kernels instead of materialising them
 K2_ON_THE_FLY = __import__("os").environ.get("HPCS_K2", "1") != "0"
+# edge-level EdgeConv layers (conv2 / conv4: 21 -> 21 channels on [B,21,3,N*k]) re-form their pre-activations on the matrix
+# cores in every pass instead of materialising them (csrc/vn_recompute.hip); HPCS_RC=0: the streaming kernels (A/B)
+RC_EDGE = __import__("os").environ.get("HPCS_RC", "1") != "0"
+RC_MIN_L = 4096          # positions per cloud from which the recompute kernels are used (tests lower it)
 
 
 def _need_cuda(*ts):
@@ -577,6 +581,25 @@ class VNLayerFn(torch.autograd.Function):
                 raise ValueError("xconst must be a tensor, None or 'mean'")
             xconst = torch.empty(B, Cin, 3, device=x.device, dtype=torch.float32)
             call("hpcs_rowsum", x, B * Cin * 3, L, 1.0 / L, xconst)
+        ctx.rc = bool(RC_EDGE and xconst is None and Cd == Cout and L >= RC_MIN_L and
+                      call("hpcs_vn_rc_supported", Cin, Cout, Cd, L, pool_k, flags))
+        if ctx.rc:
+            # no pre-activation tensor: statistics and apply (+ mean over k) each re-form their PD tile from x
+            WxP = PreparedW(Wf, Wd_)
+            Wx = WxP.Wp
+            dev = x.device
+            mean = torch.empty(Cout, device=dev)
+            rstd = torch.empty(Cout, device=dev)
+            if training:
+                sums, ticket = _zeros64_ticket(2 * Cout, dev)
+                call("hpcs_vn_rc_stats", x, Wx, Wx.shape[1], B, Cin, Cout, L, sums, ticket, BN_EPS, BN_MOMENTUM, rmean, rvar, mean, rstd)
+            else:
+                call("hpcs_bn_finalize", None, Cout, B * L, BN_EPS, BN_MOMENTUM, rmean, rvar, mean, rstd, 0)
+            out = torch.empty((B, Cout, 3, L // pool_k) if pool_k else (B, Cout, *x.shape[2:]), device=dev)
+            call("hpcs_vn_rc_apply_fwd", x, Wx, Wx.shape[1], mean, rstd, gamma, beta, B, Cin, Cout, L, pool_k, slope, out)
+            ctx.save_for_backward(x, Wx, None, None, mean, rstd, gamma, beta)
+            ctx.cfg = (B, Cin, 0, Cout, Cd, L, pool_k, slope, flags, bool(training))
+            return out
         if xconst is not None:
             xconst = _f32c(xconst)
             Cc = xconst.shape[1]
@@ -628,10 +651,43 @@ class VNLayerFn(torch.autograd.Function):
         dev = g.device
         Ctot = Cout + Cd
         red = None
+        gx = gW = gWd = ggamma = gbeta = gxc = None
+        if ctx.rc:
+            # backward reduction and apply re-form PD from x; the apply pass writes GPD once (for the weight-gradient GEMM
+            # below, on the side stream) and forms gx = W^T GPD from the same registers: no edge-level data-gradient GEMM
+            red = _zeros64(2 * Cout, dev)
+            call("hpcs_vn_rc_bwd_reduce", x, Wx, Wx.shape[1], g, mean, rstd, gamma, beta, B, Cin, Cout, L, pool_k, slope, red)
+            GPD = torch.empty(B * Ctot * 3 * L, device=dev)
+            gx = torch.empty_like(x)
+            sg, sb = _bn_sinks(ctx.bnparams, ctx.needs_input_grad[3], ctx.needs_input_grad[4])
+            call("hpcs_vn_rc_bwd_apply", x, Wx, Wx.shape[1], g, mean, rstd, gamma, beta, red, 1 if training else 0, B, Cin, Cout, L,
+                 pool_k, slope, GPD, gx, sg, sb)
+            if ctx.hub is not None:
+                ctx.hub.take(gx)
+            if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+                Wf_, Wd_ = ctx.wparams
+                sink_f = _grad_sink((Wf_, ...)) if ctx.needs_input_grad[1] else None
+                sink_d = _grad_sink((Wd_, ...)) if ctx.needs_input_grad[2] else None
+                both = _stacked_sink(sink_f, sink_d, Cout, Cd, Cin)
+                if both is not None and sink_d is not None:
+                    _on_side_stream(lambda: gemm_GXt(GPD, x, B, Ctot, Cin, 3 * L, out=both), (GPD, x), size=Ctot * Cin)
+                elif (sink_f is not None or not ctx.needs_input_grad[1]) and (sink_d is not None or not ctx.needs_input_grad[2]):
+                    def work():
+                        gWcat = gemm_GXt(GPD, x, B, Ctot, Cin, 3 * L)
+                        if sink_f is not None:
+                            sink_f.add_(gWcat[:Cout])
+                        if sink_d is not None:
+                            sink_d.add_(gWcat[Cout:])
+                    _on_side_stream(work, (GPD, x))
+                else:
+                    gWcat = gemm_GXt(GPD, x, B, Ctot, Cin, 3 * L)
+                    gW, gWd = gWcat[:Cout], gWcat[Cout:]
+            if sg is None:
+                ggamma, gbeta = _bn_grads(ctx.bnparams, red, Cout, ctx.needs_input_grad[3], ctx.needs_input_grad[4])
+            return gx, gW, gWd, ggamma, gbeta, None, None, None, None, None, None, None, None
         if flags & VN_BN:
             red = _zeros64(2 * Cout, dev)
             call("hpcs_vn_bwd_reduce", PD, g, mean, rstd, gamma, beta, B, Cout, Cd, L, pool_k, slope, flags, red, 1)
-        gx = gW = gWd = ggamma = gbeta = gxc = None
         if (FUSED_EDGE_BACKWARD and flags == (VN_BN | VN_LRELU) and Cd == Cout and Cout <= 24 and Cin <= 48 and not Cc
                 and L % 4 == 0 and (pool_k == 0 or pool_k % 4 == 0)
                 and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]):

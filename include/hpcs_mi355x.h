@@ -447,6 +447,33 @@ int hpcs_optimal_k(const double* Z, const int64_t* y, int B, int N, int num_labe
 /* flat fp32 helpers used by the data-parallel wrapper (gradient bucket pack/unpack+scale) */
 int hpcs_scale_inplace(float* x, int64_t n, float s, hpcs_stream_t stream);
 
+/* ---- EdgeConv edge-level VN layers without their pre-activation tensor (csrc/vn_recompute.hip) -------------------------
+ * VNLinearLeakyReLU on an edge tensor (hpcs/nn/dgcnn/utils/vn_layers.py:48-77, VNBatchNorm :112-132, mean_pool :150-153;
+ * conv2 / conv4 of hpcs/nn/dgcnn/vn_dgcnn_partseg.py:66-75): every pass re-forms PD = [Wf; Wd] X on the matrix cores from
+ * X [B,Cin,3,L] instead of reading a materialised PD [B,2*Cout,3,L].  Wp = the stacked weight [2*Cout, ldw] (row-major,
+ * feature rows then direction rows); BN + VN-LeakyReLU, Cd = Cout <= 24, Cin <= 24, L % 16 == 0, pool_k in {0} or a
+ * multiple of 4 up to 64 dividing L (hpcs_vn_rc_supported).  Results equal the materialised path's (same fp32 fma chains). */
+int hpcs_vn_rc_supported(int Cin, int Cout, int Cd, int64_t L, int pool_k, int flags);
+/* sums[2*Cout] (zeroed doubles) += sum |p|+eps, sum (|p|+eps)^2; counter != NULL (one zeroed uint32): the last workgroup
+ * finalises mean / rstd / running statistics (training-mode BatchNorm), like hpcs_vn_norm_stats_finalize. */
+int hpcs_vn_rc_stats(const float* X, const float* Wp, int ldw, int B, int Cin, int Cout, int64_t L, double* sums,
+                     uint32_t* counter, float eps, float momentum, float* running_mean, float* running_var, float* mean,
+                     float* rstd, hpcs_stream_t stream);
+/* out [B,Cout,3,L], or [B,Cout,3,L/pool_k] = mean over pool_k consecutive positions (pool_k > 0) */
+int hpcs_vn_rc_apply_fwd(const float* X, const float* Wp, int ldw, const float* mean, const float* rstd, const float* gamma,
+                         const float* beta, int B, int Cin, int Cout, int64_t L, int pool_k, float slope, float* out,
+                         hpcs_stream_t stream);
+/* red[2*Cout] (zeroed doubles) += the two BatchNorm backward sums (as hpcs_vn_bwd_reduce); gout as the forward's out */
+int hpcs_vn_rc_bwd_reduce(const float* X, const float* Wp, int ldw, const float* gout, const float* mean, const float* rstd,
+                          const float* gamma, const float* beta, int B, int Cin, int Cout, int64_t L, int pool_k, float slope,
+                          double* red, hpcs_stream_t stream);
+/* GPD [B,2*Cout,3,L] = (dL/dp, dL/dd) (written once, for the weight-gradient GEMM) and gX [B,Cin,3,L] = Wp^T GPD from the
+ * same registers; ggamma / gbeta (nullable, both or neither): the BatchNorm parameter gradients are added there. */
+int hpcs_vn_rc_bwd_apply(const float* X, const float* Wp, int ldw, const float* gout, const float* mean, const float* rstd,
+                         const float* gamma, const float* beta, const double* red, int training, int B, int Cin, int Cout,
+                         int64_t L, int pool_k, float slope, float* GPD, float* gX, float* ggamma, float* gbeta,
+                         hpcs_stream_t stream);
+
 /* ---- diagnostics (no reference counterpart): a stream-ordered watchpoint on a small device region ------------------
  * hpcs_debug_snapshot copies `nbytes` (multiple of 4) of the watched region into a shadow buffer; hpcs_debug_watch
  * compares region and shadow and records in status[0] the `seq` of the first call that saw them differ (status:
