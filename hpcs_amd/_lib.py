@@ -195,6 +195,9 @@ def _raw_stream():
         return torch.cuda.current_stream().cuda_stream
 
 
+_RAW_INT = frozenset(("hpcs_version", "hpcs_vn_rc_supported", "hpcs_debug_graph_census"))     # int results, not statuses
+
+
 def _call(name, *args):
     kinds, ret = SIGNATURES[name]
     fn = _fn(name)
@@ -215,7 +218,7 @@ def _call(name, *args):
     if ai != len(args):
         raise TypeError(f"{name}: expected {ai} arguments, got {len(args)}")
     rc = fn(*conv)
-    if ret == "i" and name != "hpcs_version" and rc != 0:
+    if ret == "i" and name not in _RAW_INT and rc != 0:
         msg = _STATUS.get(rc, f"HIP error {-(rc + 1000)}" if rc <= -1000 else "unknown")
         raise HpcsNativeError(f"{name} failed: {msg} (status {rc})")
     return rc

@@ -230,10 +230,10 @@ __device__ __forceinline__ RcPrm rc_prm(const float* prm, int c) {
 // lies inside one point; goff_a / goff_b = g * 12 Np + pt, g * 6 Np + pt.  Un-pooled: the lane offsets of RcOff.
 template <int SG, bool POOL>
 __device__ __forceinline__ void rc_load_g(const float* __restrict__ gs, int64_t L, int pool_k, unsigned goff_a, unsigned goff_b,
-                                          bool ok, float (&g)[3]) {
+                                          unsigned goff_safe, bool ok, float (&g)[3]) {
     const int64_t plane = POOL ? L / pool_k : L;
     const float* q = gs + (int64_t)(SG < 4 ? SG : 16 + (SG - 4)) * 3 * plane;             // uniform
-    const unsigned o = SG < 4 ? goff_a : goff_b;
+    const unsigned o = SG < 4 ? goff_a : (ok ? goff_b : goff_safe);      // an absent channel reads group 0's row, zeroed below
     float v0 = q[o], v1 = (q + plane)[o], v2 = (q + 2 * plane)[o];
     if (POOL) {
         const float kf = (float)pool_k;
@@ -459,7 +459,8 @@ __global__ __launch_bounds__(RC_TPB, 2) void vn_rc_bwd_reduce_kernel(const float
         const unsigned pt = POOL ? (unsigned)((l0 / 4 + (n >> 2)) / (pool_k / 4)) : 0u;
         const unsigned Np3 = POOL ? 3u * (unsigned)(L / pool_k) : 0u;
         const unsigned goff_a = POOL ? g * 4u * Np3 + pt : off.a;
-        const unsigned goff_b = POOL ? (16 + 2 * g + 1 < Cout ? g : 0) * 2u * Np3 + pt : (16 + 2 * g + 1 < Cout ? off.b : (unsigned)n);
+        const unsigned goff_b = POOL ? g * 2u * Np3 + pt : off.b;
+        const unsigned goff_safe = POOL ? pt : (unsigned)n;
         const float* gs = gout + b * g_cloud + (POOL ? 0 : l0);
         f32x4 acc[3][3];
         rc_recompute<true, true, true>(Aw, x, acc);
@@ -472,7 +473,7 @@ __global__ __launch_bounds__(RC_TPB, 2) void vn_rc_bwd_reduce_kernel(const float
             rc_slot_get<SG>(acc, sp.p, sp.d);                                                                            \
             vn_forward_point(sp, pr.mean, pr.rstd, pr.gamma, pr.beta, RC_FLAGS);                                         \
             float gv[3], gq[3], gd[3];                                                                                   \
-            rc_load_g<SG, POOL>(gs, L, pool_k, goff_a, goff_b, ok, gv);                                                  \
+            rc_load_g<SG, POOL>(gs, L, pool_k, goff_a, goff_b, goff_safe, ok, gv);                                       \
             vn_lrelu_bwd_point(sp, gv, slope, RC_FLAGS, gq, gd);                                                         \
             const float gnb = (gq[0] * sp.p[0] + gq[1] * sp.p[1] + gq[2] * sp.p[2]) / sp.n;                              \
             s1[SG] += ok ? gnb : 0.f;                                                                                    \
@@ -526,7 +527,8 @@ __global__ __launch_bounds__(RC_TPB, 2) void vn_rc_bwd_apply_kernel(const float*
         const unsigned pt = POOL ? (unsigned)((l0 / 4 + (n >> 2)) / (pool_k / 4)) : 0u;
         const unsigned Np3 = POOL ? 3u * (unsigned)(L / pool_k) : 0u;
         const unsigned goff_a = POOL ? g * 4u * Np3 + pt : off.a;
-        const unsigned goff_b = POOL ? (16 + 2 * g + 1 < Cout ? g : 0) * 2u * Np3 + pt : (16 + 2 * g + 1 < Cout ? off.b : (unsigned)n);
+        const unsigned goff_b = POOL ? g * 2u * Np3 + pt : off.b;
+        const unsigned goff_safe = POOL ? pt : (unsigned)n;
         const float* gs = gout + b * g_cloud + (POOL ? 0 : l0);
         int lane_o = lane;
         asm volatile("" : "+v"(lane_o));                                  // opaque: the weight reads stay inside the loop
@@ -542,7 +544,7 @@ __global__ __launch_bounds__(RC_TPB, 2) void vn_rc_bwd_apply_kernel(const float*
             rc_slot_get<SG>(acc, sp.p, sp.d);                                                                            \
             vn_forward_point(sp, pr.mean, pr.rstd, pr.gamma, pr.beta, RC_FLAGS);                                         \
             float gv[3], gq[3], gd[3], gp[3];                                                                            \
-            rc_load_g<SG, POOL>(gs, L, pool_k, goff_a, goff_b, ok, gv);                                                  \
+            rc_load_g<SG, POOL>(gs, L, pool_k, goff_a, goff_b, goff_safe, ok, gv);                                       \
             vn_lrelu_bwd_point(sp, gv, slope, RC_FLAGS, gq, gd);                                                         \
             vn_bn_bwd_point(sp, gq, true, training != 0, pr.m1, pr.m2, pr.gamma, pr.rstd, gp);                           \
             if (!ok) { gp[0] = gp[1] = gp[2] = 0.f; gd[0] = gd[1] = gd[2] = 0.f; }                                        \
