@@ -16,9 +16,11 @@ FUSED_EDGE_BACKWARD = bool(__import__("os").environ.get("HPCS_FUSED_BWD"))
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 # conv1 (two input channels) forms its pre-activations inside the point-wise kernels instead of materialising them
 K2_ON_THE_FLY = __import__("os").environ.get("HPCS_K2", "1") != "0"
-# edge-level EdgeConv layers (conv2 / conv4: 21 -> 21 channels on [B,21,3,N*k]) re-form their pre-activations on the matrix
-# cores in every pass instead of materialising them (csrc/vn_recompute.hip); HPCS_RC=0: the streaming kernels (A/B)
-RC_EDGE = __import__("os").environ.get("HPCS_RC", "1") != "0"
+# HPCS_RC=1: edge-level EdgeConv layers (conv2 / conv4: 21 -> 21 channels on [B,21,3,N*k]) re-form their pre-activations on the
+# matrix cores in every pass instead of materialising them (csrc/vn_recompute.hip: half the HBM traffic of that chain).  OPT-IN:
+# measured slower in the step (10.13 against 9.42 ms) -- the chain is bound by the VALU cost of the VN point-wise arithmetic,
+# which the recompute kernels pay at two waves per SIMD (profiles/r04_rc_experiment.md).  Tested equal to the streaming path.
+RC_EDGE = __import__("os").environ.get("HPCS_RC", "0") == "1"
 RC_MIN_L = 4096          # positions per cloud from which the recompute kernels are used (tests lower it)
 
 
