@@ -26,7 +26,7 @@ os.environ.setdefault("HPCS_GC_FREEZE", "1")
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TF = 157.3     # MI355X_MICROARCH.md: fp32 matrix peak (v_mfma_f32_32x32x2_f32)
-VALU_F32_PEAK_TF = 78.6      # MI355X_MICROARCH.md: fp32 vector peak, scalar v_fma_f32 (157 packed)
+VALU_F32_PEAK_TF = 157.3     # MI355X_MICROARCH.md:41 fp32 vector peak (packed v_pk_fma_f32; 78.6 with scalar v_fma_f32 only)
 L2_GATHER_PEAK_GBS = 17800.0  # MI355X_MICROARCH.md "Indexed rows": L2-resident row gather, 16.8-18.8 TB/s chip-wide
 
 
@@ -169,7 +169,7 @@ def cpu_baseline(args, Bc=None, points=None, k=None, num_class=None, timed_steps
     if Bc is None:
         Bc = 8 if points >= 1024 else args.batch
     if timed_steps is None:
-        timed_steps = 1 if points >= 1024 else 3
+        timed_steps = 3              # (r03: one step -- a single sample with a +-12 % spread run to run)
     # the GPU box gives one GPU a 16-core share although os.cpu_count() reports the whole host
     cores = max(1, min(len(os.sched_getaffinity(0)), 16))
     torch.set_num_threads(cores)
@@ -214,15 +214,19 @@ def cpu_baseline(args, Bc=None, points=None, k=None, num_class=None, timed_steps
     one(2, min(points, 256), min(k, 10), 6)         # warm-up on a small geometry (pages torch in, starts the thread pools)
     print(f"[bench] cpu_baseline warm-up step {time.perf_counter() - t0:.1f}s", file=sys.stderr, flush=True)
     t0 = time.perf_counter()
+    per = []
     for i in range(timed_steps):
+        t1 = time.perf_counter()
         one(Bc, points, k, 7)
+        per.append(time.perf_counter() - t1)
         print(f"[bench] cpu_baseline step {i + 1}/{timed_steps} at {time.perf_counter() - t0:.1f}s", file=sys.stderr, flush=True)
-    dt = (time.perf_counter() - t0) / timed_steps
+    dt = sorted(per)[len(per) // 2]                                   # median step
     return {"value": round(Bc / dt, 4), "unit": "point-clouds/s", "cores": cores, "kind": "port",
             "sample": f"oracle full step (fwd+loss+bwd+RAdam), B={Bc}, N={points}, k={k}, E={args.embedding}, "
-                      f"C={num_class}, {timed_steps} timed step(s) after a small-geometry warm-up, torch "
+                      f"C={num_class}, median of {timed_steps} timed step(s) after a small-geometry warm-up, torch "
                       f"{torch.get_num_threads()} threads",
-            "s_per_step": round(dt, 3)}
+            "s_per_step": round(dt, 3), "s_per_step_all": [round(v, 3) for v in per],
+            "value_min_max": [round(Bc / max(per), 4), round(Bc / min(per), 4)]}
 
 
 def knn_steady_state(dev, N, k, B=4096, D=3, reps=5):

@@ -1016,7 +1016,6 @@ static size_t nb_lds_bytes() {
     static const size_t bytes = [] {
         const size_t b = (size_t)2 * NB_BK * 2 * NB_P * sizeof(float);
         (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
-        (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
         return b;
     }();
     return bytes;
@@ -1298,11 +1297,10 @@ static int gemm_nt_impl(const float* G, int ldg, int64_t strideG_o, int64_t stri
     NtFuse fuse{nullptr, stage, dW, lddw, accumulate, slice_len, slices, 0u, 0u};
     const size_t rtiles = (size_t)p.tilesM * p.tilesK * (p.tile == 128 ? 4 : 1);      // reduction units: 64 x 64 quarters of a big tile
     if (tickets && n_tickets < rtiles * (slices + 1)) return HPCS_ERR_WORKSPACE;
-    // gemm_nt_big_kernel can reduce its splits in the launch as well (64 x 64 quarter tiles through nt_fused_reduce), but the four
-    // staged quarters + tickets cost it ~75 us (392 / 687 us against 316 / 614 us + two split_reduce launches) and the step
-    // is the same within noise (10.08-10.10 vs 10.05-10.13 ms): off by default, HPCS_NT_BIG_FUSED=1 turns it on.
-    static const bool big_fused = [] { const char* e = getenv("HPCS_NT_BIG_FUSED"); return e ? atoi(e) != 0 : false; }();
-    if (tickets && (p.tile != 128 || big_fused)) {
+    // (gemm_nt_big_kernel's own in-launch reduction -- 64 x 64 quarter tiles through nt_fused_reduce -- cost it ~75 us per launch,
+    // 392 / 687 us against 316 / 614 us + two split_reduce launches, with the step unchanged: measured in round 3, the
+    // instantiation and its switch were removed in round 4; the 128-tile kernel writes plain partials)
+    if (tickets && p.tile != 128) {
         const size_t te = edge ? (size_t)NE_T * NE_T : (p.tile == 128 ? (size_t)64 * 64 : (size_t)p.tile * p.tile);
         const size_t pb = (size_t)p.nsplit * rtiles * te * sizeof(float);
         const size_t sb = (size_t)slices * rtiles * te * sizeof(float);
@@ -1316,10 +1314,6 @@ static int gemm_nt_impl(const float* G, int ldg, int64_t strideG_o, int64_t stri
         hipLaunchKernelGGL(gemm_nt_edge_kernel, dim3((unsigned)blocks), dim3(256), 0, st, G, ldg, strideG_o, strideG_i, X, ldx,
                            strideX_o, strideX_i, M, Kx, Nc, n_inner, nb, p.chunk, p.units_per_batch, p.nsplit, (float*)ws, vecG,
                            vecX, fuse);
-    else if (p.tile == 128 && fuse.tickets)
-        hipLaunchKernelGGL(gemm_nt_big_kernel<true>, dim3((unsigned)blocks), dim3(256), nb_lds_bytes(), st, G, ldg, strideG_o, strideG_i, X,
-                           ldx, strideX_o, strideX_i, M, Kx, Nc, n_inner, nb, p.chunk, p.units_per_batch, p.nsplit, (float*)ws,
-                           p.tilesM, p.tilesK, vecG, vecX, fuse);
     else if (p.tile == 128)
         hipLaunchKernelGGL(gemm_nt_big_kernel<false>, dim3((unsigned)blocks), dim3(256), nb_lds_bytes(), st, G, ldg, strideG_o, strideG_i, X,
                            ldx, strideX_o, strideX_i, M, Kx, Nc, n_inner, nb, p.chunk, p.units_per_batch, p.nsplit, (float*)ws,

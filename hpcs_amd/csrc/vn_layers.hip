@@ -911,204 +911,6 @@ __global__ __launch_bounds__(TPB) void vn_bwd_apply_shared_vec_kernel(
         }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Fused backward of an EdgeConv VN layer (BN + VN-LeakyReLU, Cd == Cout <= 24, Cin <= 48): per 32-position tile of one
-// cloud, (1) the point-wise backward writes (dL/dp, dL/dd) = GPD [Ctot x 96] into LDS instead of HBM, (2) the input
-// tile X [Cin x 96] is staged next to it, (3) gX = W^T GPD (MFMA, K = Ctot) is stored, (4) dW += GPD X^T (MFMA,
-// K = 96 positions) accumulates in registers over all tiles of the persistent workgroup.  Against the three separate
-// kernels (bwd_apply, data-grad GEMM, weight-grad GEMM) the 330 MB GPD tensor is never written nor read twice:
-// HBM traffic per layer 2.15 GB -> 1.0 GB.  Same point-wise code (vn_forward_point / vn_lrelu_bwd_point /
-// vn_bn_bwd_point) and the same MFMA (exact fp32 fma chains) as the unfused kernels.
-typedef float f32x16_t __attribute__((ext_vector_type(16)));
-constexpr int FB_TL = 32;                 // positions per tile
-constexpr int FB_COLS = 3 * FB_TL;        // (xyz, position) columns
-constexpr int FB_P = FB_COLS + 1;         // odd LDS pitch: the weight-grad operand fetch walks rows at a fixed column
-constexpr int FB_ROWS = 48;               // >= Ctot, >= Cin
-constexpr int FB_CMAX = 24;               // Cout <= 24
-__global__ __launch_bounds__(256) void vn_bwd_fused_kernel(
-    const float* __restrict__ PD, const float* __restrict__ gout, const float* __restrict__ X, const float* __restrict__ W,
-    int ldw, const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
-    const float* __restrict__ beta, const double* __restrict__ red, int training, int B, int Cout, int Cin, int64_t L,
-    int pool_k, float slope, float* __restrict__ gX, float* __restrict__ dWpart, int tiles_per_cloud, int total_tiles) {
-    __shared__ float GPDs[FB_ROWS][FB_P];
-    __shared__ float Xs[FB_ROWS][FB_P];
-    __shared__ float Ws[FB_ROWS][64];
-    __shared__ float chp[6][FB_CMAX];
-    const int Ctot = 2 * Cout;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int lr = lane & 31, lk = lane >> 5;
-    const int flags = HPCS_VN_BN | HPCS_VN_LRELU;
-    for (int i = tid; i < FB_ROWS * 64; i += 256) {
-        const int m = i >> 6, ci = i & 63;
-        Ws[m][ci] = (m < Ctot && ci < Cin) ? W[(int64_t)m * ldw + ci] : 0.f;
-    }
-    for (int i = tid; i < FB_ROWS * FB_P; i += 256) {
-        (&GPDs[0][0])[i] = 0.f;
-        (&Xs[0][0])[i] = 0.f;
-    }
-    if (tid < Cout) {
-        const double count = (double)B * (double)L;
-        const float ga = gamma[tid];
-        chp[0][tid] = mean[tid];
-        chp[1][tid] = rstd[tid];
-        chp[2][tid] = ga;
-        chp[3][tid] = beta[tid];
-        chp[4][tid] = training ? (float)(red[tid] / count) * ga : 0.f;
-        chp[5][tid] = training ? (float)(red[Cout + tid] / count) * ga : 0.f;
-    }
-    f32x16_t accw;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) accw[r] = 0.f;
-    const int wti = w >> 1, wtj = w & 1;                     // this wave's 32x32 tile of dW [Ctot x Cin]
-    const bool w_active = wtj * 32 < Cin;
-    const int nd_tiles = 3 * (Cin > 32 ? 2 : 1);             // gX tiles: (row tile of Cin) x (xyz plane)
-    __syncthreads();
-
-    // Software pipeline over the tiles: the next tile's operands (16-byte loads: four consecutive positions per lane) are
-    // requested right after the barrier that publishes the current tile in LDS and land during its MFMA phase.
-    constexpr int XQ = FB_ROWS * 3 * (FB_TL / 4) / 256 + 1;         // float4 of the X tile per thread (<= 5)
-    const bool ew = tid < Cout * (FB_TL / 4);                       // this thread owns (channel ec, positions 4*eq..4*eq+3)
-    const int ec = tid / (FB_TL / 4), eq = tid % (FB_TL / 4);
-    float4 rp[3], rd[3], rg[3], rx[XQ];
-    auto prefetch = [&](int tile) {
-        const int b = tile / tiles_per_cloud;
-        const int64_t l0 = (int64_t)(tile % tiles_per_cloud) * FB_TL;
-        if (ew) {
-            const int64_t l = l0 + 4 * eq;
-            const bool ok = l < L;                                   // L % 4 == 0: whole vectors
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-                rp[a] = ok ? *reinterpret_cast<const float4*>(PD + (((int64_t)b * Ctot + ec) * 3 + a) * L + l) : z;
-                rd[a] = ok ? *reinterpret_cast<const float4*>(PD + (((int64_t)b * Ctot + Cout + ec) * 3 + a) * L + l) : z;
-                if (pool_k > 0) {
-                    const int64_t Np = L / pool_k;
-                    const float gsc = ok ? gout[(((int64_t)b * Cout + ec) * 3 + a) * Np + l / pool_k] / (float)pool_k : 0.f;
-                    rg[a] = make_float4(gsc, gsc, gsc, gsc);         // pool_k % 4 == 0: the four positions share the point
-                } else {
-                    rg[a] = ok ? *reinterpret_cast<const float4*>(gout + (((int64_t)b * Cout + ec) * 3 + a) * L + l) : z;
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < XQ; ++i) {
-            const int f = tid + i * 256;
-            const int ci = f / (3 * (FB_TL / 4)), rem = f % (3 * (FB_TL / 4));
-            const int a = rem / (FB_TL / 4), q = rem % (FB_TL / 4);
-            const int64_t l = l0 + 4 * q;
-            rx[i] = (ci < Cin && l < L) ? *reinterpret_cast<const float4*>(X + (((int64_t)b * Cin + ci) * 3 + a) * L + l)
-                                        : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    if ((int)blockIdx.x < total_tiles) prefetch(blockIdx.x);
-
-    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
-        const int b = tile / tiles_per_cloud;
-        const int64_t l0 = (int64_t)(tile % tiles_per_cloud) * FB_TL;
-        // (1) point-wise backward of the prefetched positions -> GPDs
-        if (ew) {
-            const float pv[3][4] = {{rp[0].x, rp[0].y, rp[0].z, rp[0].w}, {rp[1].x, rp[1].y, rp[1].z, rp[1].w}, {rp[2].x, rp[2].y, rp[2].z, rp[2].w}};
-            const float dv[3][4] = {{rd[0].x, rd[0].y, rd[0].z, rd[0].w}, {rd[1].x, rd[1].y, rd[1].z, rd[1].w}, {rd[2].x, rd[2].y, rd[2].z, rd[2].w}};
-            const float gv[3][4] = {{rg[0].x, rg[0].y, rg[0].z, rg[0].w}, {rg[1].x, rg[1].y, rg[1].z, rg[1].w}, {rg[2].x, rg[2].y, rg[2].z, rg[2].w}};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float gp[3] = {0.f, 0.f, 0.f}, gd[3] = {0.f, 0.f, 0.f};
-                if (l0 + 4 * eq + j < L) {
-                    VnPoint sp;
-                    float g[3], gq[3];
-#pragma unroll
-                    for (int a = 0; a < 3; ++a) {
-                        sp.p[a] = pv[a][j];
-                        sp.d[a] = dv[a][j];
-                        g[a] = gv[a][j];
-                    }
-                    vn_forward_point(sp, chp[0][ec], chp[1][ec], chp[2][ec], chp[3][ec], flags);
-                    vn_lrelu_bwd_point(sp, g, slope, flags, gq, gd);
-                    vn_bn_bwd_point(sp, gq, true, training != 0, chp[4][ec], chp[5][ec], chp[2][ec], chp[1][ec], gp);
-                }
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    GPDs[ec][a * FB_TL + 4 * eq + j] = gp[a];
-                    GPDs[Cout + ec][a * FB_TL + 4 * eq + j] = gd[a];
-                }
-            }
-        }
-        // (2) input tile -> Xs
-#pragma unroll
-        for (int i = 0; i < XQ; ++i) {
-            const int f = tid + i * 256;
-            const int ci = f / (3 * (FB_TL / 4)), rem = f % (3 * (FB_TL / 4));
-            if (ci < Cin) {
-                float* dst = &Xs[ci][(rem / (FB_TL / 4)) * FB_TL + 4 * (rem % (FB_TL / 4))];
-                dst[0] = rx[i].x; dst[1] = rx[i].y; dst[2] = rx[i].z; dst[3] = rx[i].w;
-            }
-        }
-        __syncthreads();
-        if (tile + (int)gridDim.x < total_tiles) prefetch(tile + gridDim.x);
-        // (3) data gradient: gX[ci][a, pos] = sum_m W[m][ci] GPD[m][a, pos]
-        for (int u = w; u < nd_tiles; u += 4) {
-            const int rt = u / 3, ct = u % 3;
-            f32x16_t acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            const int ksteps = (Ctot + 1) >> 1;
-            for (int kk = 0; kk < ksteps; ++kk) {
-                const float av = Ws[kk * 2 + lk][rt * 32 + lr];
-                const float bv = GPDs[kk * 2 + lk][ct * FB_TL + lr];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
-            }
-            const int64_t l = l0 + lr;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ci = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                if (ci < Cin && l < L) gX[(((int64_t)b * Cin + ci) * 3 + ct) * L + l] = acc[r];
-            }
-        }
-        // (4) weight gradient: dW[m][ci] += sum_col GPD[m][col] X[ci][col]
-        if (w_active) {
-            const int mrow = wti * 32 + lr, crow = wtj * 32 + lr;
-            const bool mok = mrow < FB_ROWS, cok = crow < FB_ROWS;
-#pragma unroll 4
-            for (int kk = 0; kk < FB_COLS / 2; ++kk) {
-                const float av = mok ? GPDs[mrow][kk * 2 + lk] : 0.f;
-                const float bv = cok ? Xs[crow][kk * 2 + lk] : 0.f;
-                accw = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, accw, 0, 0, 0);
-            }
-        }
-        __syncthreads();
-    }
-    if (w_active) {
-        float* P = dWpart + (int64_t)blockIdx.x * Ctot * Cin;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = wti * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-            const int ci = wtj * 32 + lr;
-            if (m < Ctot && ci < Cin) P[m * Cin + ci] = accw[r];
-        }
-    }
-}
-
-// dW [M x Kx] (row pitch lddw) = (accumulate ? dW : 0) + sum over the nparts partials, in a fixed order
-__global__ __launch_bounds__(1024) void partials_reduce_kernel(const float* __restrict__ part, int nparts, int M, int Kx,
-                                                               float* __restrict__ dW, int lddw, int accumulate) {
-    __shared__ float sh[16][64];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t e = (int64_t)blockIdx.x * 64 + lane;
-    const int64_t ne = (int64_t)M * Kx;
-    float sacc = 0.f;
-    if (e < ne)
-        for (int i = w; i < nparts; i += 16) sacc += part[(int64_t)i * ne + e];
-    sh[w][lane] = sacc;
-    __syncthreads();
-    if (w == 0 && e < ne) {
-        float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) t += sh[i][lane];
-        float* d = dW + (int64_t)(e / Kx) * lddw + (e % Kx);
-        *d = accumulate ? *d + t : t;
-    }
-}
-
 // ------------------------------------------------------------------------------ Conv1d heads: BN1d + act + mask
 __global__ void bn_stats_kernel(const float* __restrict__ Y, int B, int C, int64_t L, double* __restrict__ sums, BnFin fin) {
     __shared__ double red[16];
@@ -2470,46 +2272,6 @@ extern "C" int hpcs_vn_bwd_apply_k2(const float* E, const float* W2, int ldw, co
                              ggamma, gbeta);
 }
 
-static int fused_grid(int B, int64_t L) {
-    const int64_t tiles = (int64_t)B * hpcs_cdiv(L, FB_TL);
-    return (int)(tiles < 768 ? tiles : 768);               // persistent: 3 workgroups per CU by LDS
-}
-
-extern "C" size_t hpcs_vn_bwd_fused_workspace(int B, int Cout, int Cin, int64_t L) {
-    if (B <= 0 || Cout <= 0 || Cin <= 0 || L <= 0) return 0;
-    return (size_t)fused_grid(B, L) * 2 * Cout * Cin * sizeof(float);
-}
-
-extern "C" int hpcs_vn_bwd_fused(const float* PD, const float* gout, const float* X, const float* W, int ldw, const float* mean,
-                                 const float* rstd, const float* gamma, const float* beta, const double* red, int training,
-                                 int B, int Cout, int Cin, int64_t L, int pool_k, float slope, float* gX, float* dW, int lddw,
-                                 int dw_accumulate, void* ws, size_t ws_bytes, hpcs_stream_t stream) {
-    if (!PD || !gout || !X || !W || !mean || !rstd || !gamma || !beta || !gX || !dW || !ws) return HPCS_ERR_NULL;
-    if (training && !red) return HPCS_ERR_NULL;
-    if (B < 0 || Cout <= 0 || Cin <= 0 || L <= 0 || ldw < Cin || lddw < Cin) return HPCS_ERR_SHAPE;
-    if (pool_k < 0 || (pool_k > 0 && L % pool_k != 0)) return HPCS_ERR_SHAPE;
-    if (Cout > FB_CMAX || 2 * Cout > FB_ROWS || Cin > FB_ROWS || (int64_t)B * hpcs_cdiv(L, FB_TL) > 0x7fffffffLL)
-        return HPCS_ERR_UNSUPPORTED;
-    // 16-byte operand loads: L % 4 == 0, aligned bases, and pooled layers with pool_k % 4 == 0
-    if (L % 4 != 0 || (pool_k > 0 && pool_k % 4 != 0) || (((uintptr_t)PD | (uintptr_t)X) & 15u) ||
-        (pool_k == 0 && ((uintptr_t)gout & 15u)))
-        return HPCS_ERR_UNSUPPORTED;
-    if (B == 0) return HPCS_OK;
-    if (ws_bytes < hpcs_vn_bwd_fused_workspace(B, Cout, Cin, L)) return HPCS_ERR_WORKSPACE;
-    const int tiles_per_cloud = hpcs_cdiv(L, FB_TL);
-    const int total = B * tiles_per_cloud;
-    const int grid = fused_grid(B, L);
-    hipLaunchKernelGGL(vn_bwd_fused_kernel, dim3(grid), dim3(256), 0, ST, PD, gout, X, W, ldw, mean, rstd, gamma, beta, red,
-                       training, B, Cout, Cin, L, pool_k, slope, gX, (float*)ws, tiles_per_cloud, total);
-    HPCS_CHECK_LAUNCH();
-    const int64_t ne = (int64_t)2 * Cout * Cin;
-    hipLaunchKernelGGL(partials_reduce_kernel, dim3((unsigned)hpcs_cdiv(ne, 64)), dim3(1024), 0, ST, (const float*)ws, grid,
-                       2 * Cout, Cin, dW, lddw, dw_accumulate);
-    HPCS_CHECK_LAUNCH();
-    return HPCS_OK;
-}
-
-// ---- EdgeConv gather layers: same kernels, pre-activations formed from the point-level products UV -------------
 static int edge_args_ok(const void* UV, const void* idx, int B, int N, int k) {
     if (!UV || !idx) return HPCS_ERR_NULL;
     if (B < 0 || N <= 0 || k <= 0) return HPCS_ERR_SHAPE;

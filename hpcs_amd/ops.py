@@ -9,10 +9,6 @@ from . import _lib
 
 call = _lib.call
 VN_BN, VN_LRELU = 1, 2
-# hpcs_vn_bwd_fused (point-wise backward + data-grad + weight-grad of an EdgeConv layer in one kernel, GPD kept in LDS)
-# halves the HBM traffic of that chain but measures SLOWER than the three streaming kernels (650-740 us against
-# 150 + 180 + 230 us with the weight gradient on the side stream): opt-in, tested equal.
-FUSED_EDGE_BACKWARD = bool(__import__("os").environ.get("HPCS_FUSED_BWD"))
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 # conv1 (two input channels) forms its pre-activations inside the point-wise kernels instead of materialising them
 K2_ON_THE_FLY = __import__("os").environ.get("HPCS_K2", "1") != "0"
@@ -690,26 +686,6 @@ class VNLayerFn(torch.autograd.Function):
         if flags & VN_BN:
             red = _zeros64(2 * Cout, dev)
             call("hpcs_vn_bwd_reduce", PD, g, mean, rstd, gamma, beta, B, Cout, Cd, L, pool_k, slope, flags, red, 1)
-        if (FUSED_EDGE_BACKWARD and flags == (VN_BN | VN_LRELU) and Cd == Cout and Cout <= 24 and Cin <= 48 and not Cc
-                and L % 4 == 0 and (pool_k == 0 or pool_k % 4 == 0)
-                and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]):
-            # EdgeConv layers: point-wise backward + data gradient + weight gradient in one pass (GPD never reaches HBM)
-            gx = torch.empty(B * Cin * 3 * L, device=dev)
-            dWcat = torch.empty(Ctot, Cin, device=dev)
-            nbytes = call("hpcs_vn_bwd_fused_workspace", B, Cout, Cin, L)
-            ws = torch.empty(nbytes // 4 + 4, device=dev)
-            call("hpcs_vn_bwd_fused", PD, g, x, Wx, Wx.shape[1], mean, rstd, gamma, beta, red, 1 if training else 0, B, Cout,
-                 Cin, L, pool_k, slope, gx, dWcat, Cin, 0, ws, nbytes)
-            gx = gx.view_as(x)
-            Wf_, Wd_ = ctx.wparams
-            sink_f, sink_d = _grad_sink((Wf_, ...)), _grad_sink((Wd_, ...))
-            if sink_f is not None and sink_d is not None:
-                sink_f.add_(dWcat[:Cout])
-                sink_d.add_(dWcat[Cout:])
-            else:
-                gW, gWd = dWcat[:Cout], dWcat[Cout:]
-            ggamma, gbeta = _bn_grads(ctx.bnparams, red, Cout, ctx.needs_input_grad[3], ctx.needs_input_grad[4])
-            return gx, gW, gWd, ggamma, gbeta, None, None, None, None, None, None, None, None
         GPD = torch.empty(B * Ctot * 3 * L, device=dev)
         sg, sb = _bn_sinks(ctx.bnparams, ctx.needs_input_grad[3], ctx.needs_input_grad[4]) if (flags & VN_BN) else (None, None)
         call("hpcs_vn_bwd_apply", PD, g, mean, rstd, gamma, beta, red, 1 if training else 0, B, Cout, Cd, L, pool_k, slope,

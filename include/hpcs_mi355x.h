@@ -167,18 +167,6 @@ int hpcs_vn_bwd_apply_k2(const float* E, const float* W2, int ldw, const float* 
                          const float* rstd, const float* gamma, const float* beta, const double* red, int training, int B,
                          int Cout, int Cd, int64_t L, int pool_k, float slope, int flags, float* GPD, float* ggamma,
                          float* gbeta, hpcs_stream_t stream);
-/* Fused backward of a BN + VN-LeakyReLU layer with Cd == Cout <= 24 and Cin <= 48 (the EdgeConv layers): the point-wise
- * backward (= hpcs_vn_bwd_apply), the data gradient gX [B,Cin,3,L] = W^T GPD and the weight gradient
- * dW [2*Cout, Cin] (row pitch lddw; added to when dw_accumulate != 0) = sum GPD X^T in ONE pass: GPD stays in LDS.
- * W [2*Cout, Cin] row-major with pitch ldw (= [W_feat; W_dir]); red = output of hpcs_vn_bwd_reduce; gout is
- * [B,Cout,3,L], or [B,Cout,3,L/pool_k] when pool_k > 0.  ws: hpcs_vn_bwd_fused_workspace bytes (per-workgroup partial
- * weight gradients, reduced in a fixed order). */
-size_t hpcs_vn_bwd_fused_workspace(int B, int Cout, int Cin, int64_t L);
-int hpcs_vn_bwd_fused(const float* PD, const float* gout, const float* X, const float* W, int ldw, const float* mean,
-                      const float* rstd, const float* gamma, const float* beta, const double* red, int training, int B,
-                      int Cout, int Cin, int64_t L, int pool_k, float slope, float* gX, float* dW, int lddw,
-                      int dw_accumulate, void* ws, size_t ws_bytes, hpcs_stream_t stream);
-
 /* ---- EdgeConv "gather" layers: get_graph_feature + VNLinearLeakyReLU without the N*k tensors ----------------
  * The first VN layer of an EdgeConv block sees (x[nbr]-x[ctr], x[ctr]) (vn_dgcnn_util.py:33-39), so
  * W [x_nbr - x_ctr; x_ctr] = W_a x_nbr + (W_b - W_a) x_ctr.  UV [B, 2*Ctot, 3, N] holds the point-level products

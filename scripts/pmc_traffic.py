@@ -22,7 +22,7 @@ import sys
 WIDE = ("gemm_tn_kernel", "gemm_nt_kernel", "gemm_nt_big_kernel", "gemm_nt_edge_kernel", "_vec_kernel", "vn_bwd_apply_kernel",
         "vn_apply_pool_fwd_kernel", "vn_apply_pool_tile_kernel", "k2all_kernel", "edge_gather_bwd_center",
         "edge_segsum_kernel", "edge_gather_bwd_inv_kernel", "edge_grad_reduce_inv_kernel", "edge_grad_reduce_slab_kernel",
-        "rowsum_wave_kernel", "rowsum_long_kernel", "vn_bwd_fused_kernel", "hpcs_zero_kernel")
+        "rowsum_wave_kernel", "rowsum_long_kernel", "vn_rc_stats_kernel", "vn_rc_apply_fwd_kernel", "vn_rc_bwd_reduce_kernel", "vn_rc_bwd_apply_kernel", "hpcs_zero_kernel")
 # 16 B/lane row GATHERS (random rows through L2): the x2 rule is calibrated for streaming reads only -> reported uncorrected
 GATHER = ("hyphc_sampled", "hyphc_kernel", "knn_mfma", "edge_gather_fwd_kernel")
 

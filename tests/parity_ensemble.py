@@ -184,6 +184,44 @@ def run_grads(seeds=6, E=32, verbose=True):
             tot += 1
             far += e > 2.0 * max(r["torch_cpu_fp32"]["per_tensor"][n_], r["torch_gpu_fp32"]["per_tensor"][n_]) + 1e-7
     summary["tensors_further_than_2x_both"] = {"count": far, "of": tot}
+    # r04: WHICH tensors.  Per parameter tensor over all draws: geometric-mean error of each realisation,
+    # the HIP / torch ratios, and in how many draws HIP was further from fp64 than twice both torch runs.
+    per_name = {}
+    for n_ in runs[0]["hip"]["per_tensor"]:
+        h = [r["hip"]["per_tensor"][n_] for r in runs if n_ in r["hip"]["per_tensor"]]
+        c = [r["torch_cpu_fp32"]["per_tensor"][n_] for r in runs if n_ in r["hip"]["per_tensor"]]
+        g = [r["torch_gpu_fp32"]["per_tensor"][n_] for r in runs if n_ in r["hip"]["per_tensor"]]
+        per_name[n_] = {"gmean_hip": gmean(h), "gmean_cpu": gmean(c), "gmean_gpu": gmean(g),
+                        "ratio_hip_over_cpu": gmean([a_ / max(b_, 1e-300) for a_, b_ in zip(h, c)]),
+                        "ratio_hip_over_gpu": gmean([a_ / max(b_, 1e-300) for a_, b_ in zip(h, g)]),
+                        "draws_beyond_2x_both": sum(a_ > 2.0 * max(b_, c_) + 1e-7 for a_, b_, c_ in zip(h, c, g)), "draws": len(h)}
+    summary["per_tensor_over_draws"] = per_name
+
+    def family(n_):
+        if n_ == "__x__":
+            return "input cloud"
+        head = n_.split(".")[0]
+        kind = "bn" if ("bn" in n_ or n_.endswith(".bias") or ".1." in n_ and "weight" in n_) else \
+               "dir" if "map_to_dir" in n_ else "feat" if "map_to_feat" in n_ else "weight"
+        return f"{head}:{kind}"
+    fam = {}
+    for n_, v in per_name.items():
+        fam.setdefault(family(n_), []).append(v)
+    summary["per_family"] = {f: {"tensors": len(v), "ratio_hip_over_cpu": gmean([t["ratio_hip_over_cpu"] for t in v]),
+                                 "ratio_hip_over_gpu": gmean([t["ratio_hip_over_gpu"] for t in v]),
+                                 "gmean_hip": gmean([t["gmean_hip"] for t in v]),
+                                 "draws_beyond_2x_both": sum(t["draws_beyond_2x_both"] for t in v)} for f, v in sorted(fam.items())}
+    summary["outliers"] = sorted(({"tensor": n_, **v} for n_, v in per_name.items() if v["draws_beyond_2x_both"] > 0),
+                                 key=lambda d: -d["draws_beyond_2x_both"])
+    # 90 % bootstrap interval of the geometric-mean ratio HIP / torch-CPU of the all-parameter error (does it straddle 1?)
+    import random
+    rng = random.Random(0)
+    lr = [math.log(r["hip"]["all_l2"] / r["torch_cpu_fp32"]["all_l2"]) for r in runs]
+    boots = sorted(math.exp(sum(rng.choice(lr) for _ in lr) / len(lr)) for _ in range(4000))
+    summary["all_l2"]["gmean_ratio_hip_over_cpu_ci90"] = [boots[200], boots[3799]]
+    lr = [math.log(r["hip"]["all_l2"] / r["torch_gpu_fp32"]["all_l2"]) for r in runs]
+    boots = sorted(math.exp(sum(rng.choice(lr) for _ in lr) / len(lr)) for _ in range(4000))
+    summary["all_l2"]["gmean_ratio_hip_over_gpu_ci90"] = [boots[200], boots[3799]]
     for r in runs:                                   # keep the JSON small: per-tensor tables only for the first draw
         if r["seed"] > 0:
             for vn in ("hip", "torch_cpu_fp32", "torch_gpu_fp32"):

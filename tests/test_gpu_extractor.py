@@ -608,31 +608,6 @@ def test_grad_hub_and_mean_mode_equal_plain_autograd():
         relclose(a, b, 2e-5)
 
 
-@pytest.mark.parametrize("Cin,pool", [(42, True), (21, False), (2, False), (42, False)])
-def test_fused_edge_backward_equals_unfused(Cin, pool):
-    """hpcs_vn_bwd_fused (point-wise backward + data-grad + weight-grad in one pass) against the three separate kernels."""
-    from hpcs_amd import ops
-    from hpcs_amd.nn.dgcnn.utils.vn_layers import VNLinearLeakyReLU
-    B, N, k = 3, 70, 12                                # L = 840: not a multiple of the 32-position tile
-    torch.manual_seed(21)
-    layer = VNLinearLeakyReLU(Cin, 21, dim=5).to(dev).train()
-    x0 = det_normalish((B, Cin, 3, N, k), 950 + Cin)
-    res = []
-    for fused in (True, False):
-        ops.FUSED_EDGE_BACKWARD = fused
-        try:
-            layer.zero_grad(set_to_none=True)
-            xg = x0.to(dev).requires_grad_(True)
-            y = layer(xg, pool_k=k) if pool else layer(xg)
-            wgt = det_uniform(tuple(y.shape), 951).to(dev)
-            (y * wgt).sum().backward()
-        finally:
-            ops.FUSED_EDGE_BACKWARD = False              # the default (opt-in path: measured slower, kept tested)
-        res.append([xg.grad.clone()] + [p.grad.clone() for p in layer.parameters()])
-    for a, b in zip(*res):
-        relclose(a, b, 2e-5)
-
-
 def test_in_kernel_dropout_equals_explicit_mask():
     """bn_act(drop=(seed, p)) -- the multiplier generated inside the three kernels -- equals bn_act(mask=) with the tensor
     hpcs_dropout_mask materialises for the same (seed, p), forward and backward; keep rate and scale are right."""

@@ -283,41 +283,3 @@ def test_gemm_tn_graph_refuses_what_its_loader_cannot_do():
         call("hpcs_gemm_tn_graph", At, 68, feat, torch.zeros(1, 32, 6, dtype=torch.int64, device=dev), 1, 4, 32, 6, 8, out, ws, 4096)
     with pytest.raises(HpcsNativeError):                                   # more than one 64-row tile
         call("hpcs_gemm_tn_graph", At, 68, feat, torch.zeros(1, 32, 8, dtype=torch.int64, device=dev), 1, 4, 32, 8, 65, out, ws, 4096)
-
-
-@pytest.mark.gpu
-def test_gemm_nt_big_in_launch_reduction_switch():
-    """HPCS_NT_BIG_FUSED=1 (read once per process, hence a child process): the 128-tile weight-gradient kernel sums its splits in
-    the launch, one 64 x 64 quarter tile at a time; same result as the default (plain partials + split_reduce launches), fp64
-    check, tickets left zero, deterministic."""
-    import subprocess
-    import sys
-    code = r'''
-import sys, numpy as np, torch
-sys.path.insert(0, %r); sys.path.insert(0, %r)
-from hpcs_amd import _lib
-from _det import det_normalish
-dev = "cuda"
-for (M, Kx, Nc, nb) in [(340, 341, 1536, 2), (682, 341, 1000, 3), (301, 303, 77, 2)]:
-    G = det_normalish((nb, M, Nc), 600 + M).to(dev); X = det_normalish((nb, Kx, Nc), 700 + Kx).to(dev)
-    nbytes = _lib.call("hpcs_gemm_nt_workspace", M, Kx, Nc, nb, 1); nt = _lib.call("hpcs_gemm_nt_tickets", M, Kx, Nc, nb, 1)
-    ws = torch.empty(nbytes // 4 + 1, device=dev); tickets = torch.zeros(nt, dtype=torch.int32, device=dev)
-    want = torch.einsum("bmc,bkc->mk", G.double().cpu(), X.double().cpu())
-    outs = []
-    for acc in (0, 1, 1):
-        dW = torch.full((M, Kx), 3.0, device=dev)
-        _lib.call("hpcs_gemm_nt_fused", G, Nc, M * Nc, 0, X, Nc, Kx * Nc, 0, M, Kx, Nc, nb, 1, dW, Kx, acc, ws, nbytes, tickets, nt)
-        torch.cuda.synchronize()
-        assert int(tickets.abs().sum()) == 0
-        torch.testing.assert_close(dW.cpu().double(), want + (3.0 if acc else 0.0), rtol=1e-5,
-                                   atol=2e-6 * float(want.abs().max()) * np.sqrt(Nc * nb))
-        outs.append(dW.clone())
-    assert torch.equal(outs[1], outs[2])
-    ref = torch.full((M, Kx), 3.0, device=dev)
-    _lib.call("hpcs_gemm_nt", G, Nc, M * Nc, 0, X, Nc, Kx * Nc, 0, M, Kx, Nc, nb, 1, ref, Kx, 1, ws, nbytes)
-    torch.testing.assert_close(outs[1], ref, rtol=2e-6, atol=1e-6 * float(want.abs().max()))
-print("ok")
-''' % (ROOT, os.path.join(ROOT, "tests"))
-    env = dict(os.environ, HPCS_NT_BIG_FUSED="1")
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
