@@ -163,34 +163,65 @@ class HypHCSampledFn(torch.autograd.Function):
         return (gxn_raw, gscale.view_as(scale)) + (None,) * 12
 
 
+_ONES = {}
+
+
+def _ones1(device):
+    """A persistent device scalar 1.0 (the upstream gradient of the unscaled backward passes)."""
+    t = _ONES.get(device)
+    if t is None:
+        t = _ONES[device] = torch.ones(1, device=device)
+    return t
+
+
 class CosFaceFn(torch.autograd.Function):
+    """CosFace / hierarchical CosFace mean loss.  The loss is linear in its upstream gradient, so when a gradient will be
+    needed the forward also runs the backward kernel with upstream 1 (like the sampled HypHC kernel does) and backward is one
+    rescale of that buffer.  Inside the step driver's forward_side_stream() all of it is enqueued on the SIDE stream: nothing on
+    the main stream needs the CosFace branch until the two loss terms are added, so it runs beside the sampled HypHC kernel
+    (which is alone on the chip for 1.7 ms) instead of in the launch-latency-bound tail behind it -- the caller joins with
+    ops.join_forward_side() after the HypHC term has been enqueued."""
+
     @staticmethod
     def forward(ctx, xn, wn, labels, margin, scale, branch_id):
+        from .. import ops
         M, E = xn.shape
         C = wn.shape[0]
+        dev = xn.device
         n_levels = 1 if branch_id is None else branch_id.shape[0]
-        logits = torch.empty(M, C, device=xn.device, dtype=torch.float32)
-        rows = torch.empty(M, device=xn.device, dtype=torch.float32)
-        lse = torch.empty(M, device=xn.device, dtype=torch.float32)
-        call("hpcs_cosface_fwd", xn, wn, labels, branch_id, n_levels, M, E, C, margin, scale, logits, rows, lse)
-        ctx.save_for_backward(xn, wn, labels, logits, lse, branch_id)
-        ctx.cfg = (scale, n_levels)
+        logits = torch.empty(M, C, device=dev, dtype=torch.float32)
+        rows = torch.empty(M, device=dev, dtype=torch.float32)
+        lse = torch.empty(M, device=dev, dtype=torch.float32)
+        mean = torch.empty(1, device=dev, dtype=torch.float32)
+        need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        gbuf = torch.empty(M * E + C * E, device=dev, dtype=torch.float32) if need else None     # [gxn | gwn], upstream 1
+        ones = _ones1(dev) if need else None
+        side = ops.fork_forward_side()
+        with (torch.cuda.stream(side) if side is not None else _NullCtx()):
+            call("hpcs_cosface_fwd", xn, wn, labels, branch_id, n_levels, M, E, C, margin, scale, logits, rows, lse)
+            call("hpcs_rowsum", rows, 1, M, 1.0 / M, mean)
+            if need:
+                call("hpcs_cosface_bwd", xn, wn, labels, logits, lse, branch_id, n_levels, M, E, C, scale, ones,
+                     gbuf[:M * E], gbuf[M * E:])
+        ctx.save_for_backward(gbuf)
+        ctx.dims = (M, E, C)
         ctx.mark_non_differentiable(logits)
-        mean = torch.empty(1, device=xn.device, dtype=torch.float32)
-        call("hpcs_rowsum", rows, 1, M, 1.0 / M, mean)
         return mean[0], logits
 
     @staticmethod
     def backward(ctx, g, _glogits):
-        xn, wn, labels, logits, lse, branch_id = ctx.saved_tensors
-        scale, n_levels = ctx.cfg
-        M, E = xn.shape
-        C = wn.shape[0]
-        gxn = torch.empty_like(xn)                   # both zero-filled by the entry point
-        gwn = torch.empty_like(wn)
-        call("hpcs_cosface_bwd", xn, wn, labels, logits, lse, branch_id, n_levels, M, E, C, scale,
-             g.reshape(1).contiguous().float(), gxn, gwn)
-        return gxn, gwn, None, None, None, None
+        (gbuf,) = ctx.saved_tensors
+        M, E, C = ctx.dims
+        gb = gbuf * g.reshape(1).float()
+        return gb[:M * E].view(M, E), gb[M * E:].view(C, E), None, None, None, None
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
 
 
 class CosFaceLoss(torch.nn.Module):
@@ -380,12 +411,18 @@ class MetricHyperbolicLoss(torch.nn.Module):
             raise _lib.HpcsNativeError("hpcs_amd losses need HIP-device tensors (there is no CPU fallback)")
         labels = labels.reshape(-1)
         xn = L2RowsFn.apply(x_poincare)
-        loss_hyperbolic = self.compute_hyp(x_poincare, labels, plan=plan, xn=xn, step_ctx=step_ctx)
         if self.cosface:
+            # enqueued first: inside the step driver its kernels go to the side stream and run beside the HypHC kernel below
+            from ..ops import join_forward_side
             loss_metric = self.loss_cosface(x_poincare, labels.long(), xn=xn)
-        else:
-            a, p, n, count = self.triplet_miner.mine_device(x_poincare, labels, plan=plan_metric or plan, xn=xn.detach())
-            loss_metric = self.loss_triplet(x_poincare, labels, (a, p, n), count=count)
+            try:
+                loss_hyperbolic = self.compute_hyp(x_poincare, labels, plan=plan, xn=xn, step_ctx=step_ctx)
+            finally:
+                join_forward_side()
+            return {"loss_hyp": {"losses": loss_hyperbolic}, "loss_metric": {"losses": loss_metric}}
+        loss_hyperbolic = self.compute_hyp(x_poincare, labels, plan=plan, xn=xn, step_ctx=step_ctx)
+        a, p, n, count = self.triplet_miner.mine_device(x_poincare, labels, plan=plan_metric or plan, xn=xn.detach())
+        loss_metric = self.loss_triplet(x_poincare, labels, (a, p, n), count=count)
         return {"loss_hyp": {"losses": loss_hyperbolic}, "loss_metric": {"losses": loss_metric}}
 
     def make_plan(self, labels_cpu_or_counts, minlength=0):

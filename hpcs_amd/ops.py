@@ -263,6 +263,7 @@ class _SideWGrad:
     stream = None
     used = False
     keep = []
+    fwd_pending = False          # forward work was forked onto the side stream and not joined yet
 
 
 class forward_side_stream:
@@ -277,8 +278,27 @@ class forward_side_stream:
         return self
 
     def __exit__(self, *exc):
+        join_forward_side()
         _SideWGrad.forward = False
         return False
+
+
+def fork_forward_side():
+    """Inside forward_side_stream(): the side stream, made to wait for everything enqueued on the current stream so far, for
+    forward work that nothing on the main stream needs until `join_forward_side()` (the CosFace branch of the loss, which runs
+    beside the sampled HypHC kernel).  None outside that context (the caller then launches in line).  Outputs must be
+    allocated BEFORE switching streams (on the current stream), so that their blocks obey the main stream's ordering."""
+    if not _SideWGrad.forward or _SideWGrad.stream is None:
+        return None
+    _SideWGrad.stream.wait_stream(torch.cuda.current_stream())
+    _SideWGrad.fwd_pending = True
+    return _SideWGrad.stream
+
+
+def join_forward_side():
+    if _SideWGrad.fwd_pending:
+        torch.cuda.current_stream().wait_stream(_SideWGrad.stream)
+        _SideWGrad.fwd_pending = False
 
 
 class deferred_weight_grads:

@@ -601,18 +601,24 @@ def test_train_mode_gradient_error_is_torchs_over_an_ensemble():
     fp32 on the CPU and on this GPU.  Measured r03 (profiles/r03_grad_ensemble.json): the quantity is heavy-tailed for EVERY
     realisation -- all-parameter error per draw 1.2e-3 ... 1.1e-1 for HIP, 1.3e-3 ... 4.3e-2 for torch-CPU, 1.7e-3 ... 3.1e-2
     for torch-GPU; geometric mean of HIP / max(both) 0.83, of HIP / torch-GPU 1.10; the median tensor is CLOSER to fp64 on the HIP
-    path than on torch-GPU (0.51); 10 of 294 tensors further than twice both.  Bars (regression guard with that spread in mind):
+    path than on torch-GPU (0.51); 10 of 294 tensors further than twice both.
+    r04 (profiles/r04_grad_ensemble.json): 24 draws -- geometric mean HIP / torch-CPU 0.86 (90 % bootstrap interval
+    0.64 ... 1.17), HIP / torch-GPU 0.89 (0.68 ... 1.17): the six-draw "1.40x" was the spread of the quantity, not an excess; the 38
+    of 1176 tensors beyond twice both torch runs are spread over every layer family (no tensor in more than 2 of 24 draws), i.e.
+    there is no kernel to single out.  Bars, tightened to that evidence (six draws here, so a margin over the 24-draw means):
 
-        geometric mean over the draws of  err_all(HIP) / max(err_all(torch CPU), err_all(torch GPU))  <= 1.3
-        no single draw above 4x, at most 8 % of the tensors further than twice both torch realisations."""
+        geometric mean over the draws of  err_all(HIP) / max(err_all(torch CPU), err_all(torch GPU))  <= 1.15
+        geometric mean of                 err_all(HIP) / err_all(torch CPU)                             <= 1.5
+        no single draw above 3x, at most 6 % of the tensors further than twice both torch realisations."""
     import math
     import parity_ensemble as PE
     res = PE.run_grads(seeds=6, E=32, verbose=False)
-    REPORT["train_mode_gradient_ensemble_summary"] = res["summary"]
+    REPORT["train_mode_gradient_ensemble_summary"] = {k_: v for k_, v in res["summary"].items() if k_ != "per_tensor_over_draws"}
     ratios = [r["hip"]["all_l2"] / max(r["torch_cpu_fp32"]["all_l2"], r["torch_gpu_fp32"]["all_l2"]) for r in res["runs"]]
     gm = math.exp(sum(math.log(v) for v in ratios) / len(ratios))
-    assert gm <= 1.3, (gm, ratios)
-    assert max(ratios) <= 4.0, ratios
+    assert gm <= 1.15, (gm, ratios)
+    assert res["summary"]["all_l2"]["gmean_ratio_hip_over_cpu"] <= 1.5, res["summary"]["all_l2"]
+    assert max(ratios) <= 3.0, ratios
     far = res["summary"]["tensors_further_than_2x_both"]
-    assert far["count"] <= 0.08 * far["of"], far
+    assert far["count"] <= 0.06 * far["of"], far
     assert all(r["tensors"] >= 40 for r in res["runs"])
