@@ -203,6 +203,11 @@ class CosFaceFn(torch.autograd.Function):
             if need:
                 call("hpcs_cosface_bwd", xn, wn, labels, logits, lse, branch_id, n_levels, M, E, C, scale, ones,
                      gbuf[:M * E], gbuf[M * E:])
+        if side is not None:
+            # every buffer a side-stream kernel touches stays referenced until the step's streams have joined (the end of the
+            # backward pass: ops.deferred_weight_grads): a temporary freed here would go back to the MAIN stream's pool while
+            # the side stream still writes it -- `rows` [M] handed out again as the miner's class index was a GPU memory fault
+            ops._SideWGrad.keep.append((logits, rows, lse, mean, gbuf, ones, xn, wn, labels, branch_id))
         ctx.save_for_backward(gbuf)
         ctx.dims = (M, E, C)
         ctx.mark_non_differentiable(logits)
