@@ -248,6 +248,18 @@ def graph_census(cuda_graph):
     return out
 
 
+KNN_KERNEL_CODES = {"auto": 0, "tiled": 1, "queue": 2, "bq": 4, "bq2": 5}
+
+
+def set_tuning(name, value):
+    """Tests / A-B scripts: replace one value of the library's tuning table (read from the HPCS_* environment once at first
+    use, immutable otherwise).  name = the environment variable's name, value = its integer code."""
+    fn = _fn("hpcs_debug_set_tuning")
+    rc = fn(name.encode(), int(value))
+    if rc != 0:
+        raise HpcsNativeError(f"hpcs_debug_set_tuning({name!r}) failed (status {rc})")
+
+
 def exported_symbols_declared_in_header():
     """Names declared in include/hpcs_mi355x.h (used by the ABI test)."""
     return sorted(SIGNATURES)

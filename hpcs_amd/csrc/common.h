@@ -15,6 +15,24 @@
 
 static inline int hpcs_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Tuning switches (A/B experiments and fallbacks; the defaults are what the bench runs).  Read from the environment ONCE, at the
+// first entry-point call that needs one (csrc/debug.hip holds the table), and immutable afterwards: entry points keep no other
+// global state.  hpcs_debug_set_tuning (tests only) replaces a value in place.
+struct HpcsTuning {
+    int nt_wg_target;      // HPCS_NT_WG_TARGET   weight-gradient GEMM: workgroups per launch aimed for (0 = built-in)
+    int nt_big_min;        // HPCS_NT_BIG_MIN     smallest output side that takes the 128 x 128 weight-gradient kernel (300)
+    int nt_big_wg;         // HPCS_NT_BIG_WG      workgroups of that kernel (512 = two per CU)
+    int gemm_vecstore;     // HPCS_GEMM_VECSTORE  16-byte epilogue stores through LDS (1)
+    int gemm_tn_guarded;   // HPCS_GEMM_TN_GUARDED bounds-tested operand loader (0)
+    int knn_kernel;        // HPCS_KNN_KERNEL     0 auto | 1 tiled (sorting network) | 2 queue | 4 bq | 5 bq2
+    int sampled_v;         // HPCS_SAMPLED_V      sampled HypHC kernel: 4 (r03 form) | 8 (r02 form, also serves E = 64)
+    int sampled_seg;       // HPCS_SAMPLED_SEG    triplets per 8-lane group (0 = chosen per launch)
+    int sampled_lds_kb;    // HPCS_SAMPLED_LDS_KB LDS budget of its positive table (156)
+    int edge_bwd_atomic;   // HPCS_EDGE_BWD_ATOMIC graph-layer gradient reduction by atomics instead of the transposed graph (0)
+};
+extern "C" const HpcsTuning* hpcs_tuning_table(void);
+static inline const HpcsTuning& hpcs_tuning() { return *hpcs_tuning_table(); }
+
 // Zero-fill of up to four buffers as ONE ordinary kernel launch.  This library never calls hipMemsetAsync: on this runtime
 // (ROCm 7.0 / 7.2, graph packet capture on) the memset NODES of a replayed hipGraph lose their arguments once a second
 // graph has been instantiated -- after a device-wide synchronize, or after a few thousand node launches, the fill writes

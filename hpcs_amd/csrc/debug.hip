@@ -5,6 +5,9 @@
 // launch after which they differ.  Both are ordinary kernels, so they are captured into a hipGraph with the step and
 // bracket every captured node; neither allocates, so the memory layout of the run under test is unchanged.  This is how
 // the stray store of round 2 (DESIGN.md "The stray store") was attributed to its kernel.
+#include <stdlib.h>
+#include <string.h>
+
 #include "common.h"
 
 namespace {
@@ -105,4 +108,45 @@ extern "C" int hpcs_debug_graph_census(void* graph, int64_t* counts16) {
     if (!graph || !counts16) return HPCS_ERR_NULL;
     for (int i = 0; i < 16; ++i) counts16[i] = 0;
     return graph_census((hipGraph_t)graph, counts16, 0);
+}
+
+// ---- tuning table (common.h HpcsTuning): read once, then immutable -------------------------------------------------------
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return (e && *e) ? atoi(e) : dflt;
+}
+static HpcsTuning read_tuning() {
+    HpcsTuning t;
+    t.nt_wg_target = env_int("HPCS_NT_WG_TARGET", 0);
+    t.nt_big_min = env_int("HPCS_NT_BIG_MIN", 300);
+    t.nt_big_wg = env_int("HPCS_NT_BIG_WG", 512);
+    t.gemm_vecstore = env_int("HPCS_GEMM_VECSTORE", 1) != 0;
+    t.gemm_tn_guarded = env_int("HPCS_GEMM_TN_GUARDED", 0) != 0;
+    const char* k = getenv("HPCS_KNN_KERNEL");
+    t.knn_kernel = !k || !*k ? 0 : (k[0] == 't' ? 1 : (k[0] == 'b' ? (k[1] == 'q' && k[2] == '2' ? 5 : 4) : 2));
+    t.sampled_v = env_int("HPCS_SAMPLED_V", 4) == 8 ? 8 : 4;
+    t.sampled_seg = env_int("HPCS_SAMPLED_SEG", 0);
+    t.sampled_lds_kb = env_int("HPCS_SAMPLED_LDS_KB", 156);
+    t.edge_bwd_atomic = getenv("HPCS_EDGE_BWD_ATOMIC") != nullptr;
+    return t;
+}
+static HpcsTuning& tuning_storage() {
+    static HpcsTuning t = read_tuning();           // thread-safe one-time initialisation
+    return t;
+}
+extern "C" const HpcsTuning* hpcs_tuning_table(void) { return &tuning_storage(); }
+
+// Tests only: replace one value of the table (names = the environment variables' names).  Returns 0, or HPCS_ERR_SHAPE for an
+// unknown name.
+extern "C" int hpcs_debug_set_tuning(const char* name, int value) {
+    if (!name) return HPCS_ERR_NULL;
+    HpcsTuning& t = tuning_storage();
+    struct { const char* n; int* p; } tab[] = {
+        {"HPCS_NT_WG_TARGET", &t.nt_wg_target}, {"HPCS_NT_BIG_MIN", &t.nt_big_min}, {"HPCS_NT_BIG_WG", &t.nt_big_wg},
+        {"HPCS_GEMM_VECSTORE", &t.gemm_vecstore}, {"HPCS_GEMM_TN_GUARDED", &t.gemm_tn_guarded}, {"HPCS_KNN_KERNEL", &t.knn_kernel},
+        {"HPCS_SAMPLED_V", &t.sampled_v}, {"HPCS_SAMPLED_SEG", &t.sampled_seg}, {"HPCS_SAMPLED_LDS_KB", &t.sampled_lds_kb},
+        {"HPCS_EDGE_BWD_ATOMIC", &t.edge_bwd_atomic}};
+    for (auto& e : tab)
+        if (strcmp(e.n, name) == 0) { *e.p = value; return HPCS_OK; }
+    return HPCS_ERR_SHAPE;
 }

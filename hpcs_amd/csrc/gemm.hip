@@ -1028,14 +1028,10 @@ constexpr int NT_BKC = 32;      // 64-wide steps measured: +9 % on the HBM-bound
 
 struct NtPlan { int tile, tilesM, tilesK, chunk, units_per_batch, nsplit; };
 static long nt_wg_target() {
-    static long v = [] {
-        const char* e = getenv("HPCS_NT_WG_TARGET");
-        // 768 = three workgroups per CU: 2048 (eight) measured 1.3 % slower in the step, 10.25-10.29 vs 10.10-10.15 ms -- the
-        // weight gradients run next to the main stream's kernels and fewer, longer workgroups leave those more of the chip
-        long t = e ? atol(e) : 768;
-        return t < 64 ? 64 : t;
-    }();
-    return v;
+    // 768 = three workgroups per CU: 2048 (eight) measured 1.3 % slower in the step, 10.25-10.29 vs 10.10-10.15 ms -- the
+    // weight gradients run next to the main stream's kernels and fewer, longer workgroups leave those more of the chip
+    const long t = hpcs_tuning().nt_wg_target > 0 ? hpcs_tuning().nt_wg_target : 768;
+    return t < 64 ? 64 : t;
 }
 // (Measured and NOT kept, r03: capping this GEMM's residency with unused dynamic LDS -- 4 / 3 / 2 workgroups per CU instead of
 // 8 -- so that the main stream's streaming kernels find free wave slots next to it: 10.61 -> 10.55 / 10.53 / 10.58 ms per step,
@@ -1044,7 +1040,7 @@ NtPlan nt_plan(int M, int Kx, int Nc, int n_batch) {
     NtPlan p;
     const long WG = nt_wg_target();
     // 128 x 128 tiles (gemm_nt_big_kernel) from 300 x 300 outputs up: VNStdFeature's vn1 / vn2 weight gradients
-    static const int big_min = [] { const char* e = getenv("HPCS_NT_BIG_MIN"); return e ? atoi(e) : 300; }();
+    const int big_min = hpcs_tuning().nt_big_min;
     p.tile = (M >= big_min && Kx >= big_min) ? 128 : 64;
     p.tilesM = hpcs_cdiv(M, p.tile);
     p.tilesK = hpcs_cdiv(Kx, p.tile);
@@ -1073,7 +1069,7 @@ NtPlan nt_plan(int M, int Kx, int Nc, int n_batch) {
         p.units_per_batch = 1;
         const long T = (long)n_batch * hpcs_cdiv(Nc, NB_BK);
         // two workgroups per CU (512): 10.01-10.06 ms per step against 10.08-10.13 with four (1024); 256: 10.06
-        static const long big_wg = [] { const char* e = getenv("HPCS_NT_BIG_WG"); return e ? atol(e) : 512L; }();
+        const long big_wg = hpcs_tuning().nt_big_wg;
         long ns = big_wg / ((long)p.tilesM * p.tilesK);
         if (ns < 1) ns = 1;
         if (ns > T) ns = T;
@@ -1178,8 +1174,7 @@ extern "C" int hpcs_gemm_tn(const float* At, int lda, const float* Bm, int ldb, 
     hipStream_t st = (hipStream_t)stream;
     const int vecA = (lda % 4 == 0) && aligned16(At);
     const int vecB = (ldb % 4 == 0) && (strideB_o % 4 == 0) && (strideB_i % 4 == 0) && aligned16(Bm);
-    static int vecC_env = -1;
-    if (vecC_env < 0) { const char* e = getenv("HPCS_GEMM_VECSTORE"); vecC_env = e ? atoi(e) != 0 : 1; }
+    const int vecC_env = hpcs_tuning().gemm_vecstore;
     const int vecC = vecC_env && (ldc % 4 == 0) && (strideC_o % 4 == 0) && (strideC_i % 4 == 0) && aligned16(C);
     const int nb = n_outer * n_inner;
     {   // fewer than 32 tiles of 128x128 over all batches and a short enough reduction: the per-element kernel
@@ -1197,8 +1192,7 @@ extern "C" int hpcs_gemm_tn(const float* At, int lda, const float* Bm, int ldb, 
     // straight-line loader: every 16-byte load of both operands is in bounds after clamping (see tn_tile)
     const bool fast = vecA && vecB && Nc % 4 == 0 && Nc >= 4 && lda >= 4;
     // A/B switch: HPCS_GEMM_TN_GUARDED=1 forces the guarded loader
-    static int guarded = -1;
-    if (guarded < 0) { const char* e = getenv("HPCS_GEMM_TN_GUARDED"); guarded = e ? atoi(e) != 0 : 0; }
+    const int guarded = hpcs_tuning().gemm_tn_guarded;
 #define HPCS_TN_LAUNCH(BM_, WM_, WN_, FAST_)                                                                                 \
     hipLaunchKernelGGL((gemm_tn_kernel<BM_, 128, 16, WM_, WN_, FAST_>), dim3((unsigned)total), dim3(256), 0, st, At, lda, Bm,     \
                        ldb, strideB_o, strideB_i, C, ldc, strideC_o, strideC_i, M, Nc, K, n_inner, rowbias, accumulate, tm, tn,  \

@@ -7,18 +7,17 @@
 //   score  = ((-sq_j) - (-2*gram)) - sq_i ;  order = (score desc, index asc)
 // This file is compiled with -ffp-contract=off so only the explicit fmaf's fuse.
 //
-// Kernels (selection rule and measurements in launch_knn_mfma): knn_mfma_sort_kernel (k <= 32: the default), knn_mfma_queue_kernel
-// (k > 32), knn_mfma_kernel (per-score insertion: kept as the cross-check), knn_kernel (any D / no workspace).  All use the
-// same bit-defined arithmetic below.  The two original kernels:
-//  * knn_mfma_kernel (D = 3 and D = 63, k <= 40: the HPCS shapes).  One workgroup = one cloud x 32 queries, 4 waves.
+// Kernels (selection rule and measurements in launch_knn_mfma): knn_mfma_bq_kernel (k <= 32 once there is a wave per SIMD: the
+// default), knn_mfma_sort_kernel (small batches; k = 33..40 with the flagged repair), knn_mfma_queue_kernel (the exact repair /
+// k > 32 form), knn_kernel (any D / no workspace).  All use the same bit-defined arithmetic below.
+//  * The MFMA kernels (D = 3 and D = 63, k <= 40: the HPCS shapes): one workgroup = one cloud x 32 queries.
 //    The Gram tile (32 candidates x 32 queries) is produced by v_mfma_f32_32x32x2_f32 with the candidates as the A
 //    operand (fetched straight from the [D,N] slab: lanes 0-31 read 128 contiguous bytes of row d, lanes 32-63 of
 //    row d+1) and the queries as the B operand (held in registers for the whole kernel).  The f32 MFMA is a
 //    k-ordered fma chain, i.e. exactly the pinned rounding sequence.  Lane l then owns 16 scores of query l&31
-//    (rows (r&3)+8(r>>2)+4(l>>5), increasing in r), which it inserts into its private sorted top-k list.  The
-//    four waves take interleaved candidate tiles, so a query's candidates are spread over 8 lists (4 waves x 2 lane
-//    halves), each visited in ascending index order; a final 8-way merge through LDS (score desc, index asc)
-//    yields the row.  |x|^2 comes from a pre-pass into the caller's workspace.
+//    (rows (r&3)+8(r>>2)+4(l>>5), increasing in r) and selects among them (sorting network / batch queue / queue); a final
+//    merge through LDS (score desc, index asc) yields the row.  |x|^2 comes from a pre-pass into the caller's workspace.
+//    (Round 1's per-score insertion kernel, knn_mfma_kernel, was the cross-check of these until round 4; removed.)
 //  * knn_kernel (any D, k <= 64): the scalar fallback described next.
 //
 // Fallback layout / mapping: one workgroup = one cloud x QT queries (one query per thread).  The cloud's
@@ -153,98 +152,6 @@ __global__ void knn_sumsq_kernel(const float* __restrict__ x, int D, int N, int6
 
 constexpr int MQ = 32;         // queries per workgroup (MFMA column block)
 constexpr int MW = 4;          // waves per workgroup = candidate tile interleave
-
-template <int KSTEPS, int KK>
-__global__ __launch_bounds__(MW * 64) void knn_mfma_kernel(const float* __restrict__ x, const float* __restrict__ sq, int D,
-                                                           int N, int k, int64_t* __restrict__ idx) {
-    __shared__ float lval[MQ][2 * MW][KK];
-    __shared__ int lidx[MQ][2 * MW][KK];
-    const int tiles_q = (N + MQ - 1) / MQ;
-    const int b = blockIdx.x / tiles_q;
-    const int q0 = (blockIdx.x % tiles_q) * MQ;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int lr = lane & 31, lk = lane >> 5;
-    const float* xb = x + (int64_t)b * D * N;
-    const float* sqb = sq + (int64_t)b * N;
-
-    // B operand: B[k][j] = x[d = 2*kk + lk][query q0 + lr]
-    const int qi = q0 + lr;
-    const bool qok = qi < N;
-    float bq[KSTEPS];
-#pragma unroll
-    for (int kk = 0; kk < KSTEPS; ++kk) {
-        const int d = 2 * kk + lk;
-        bq[kk] = (qok && d < D) ? xb[(int64_t)d * N + qi] : 0.f;
-    }
-    const float sq_i = qok ? sqb[qi] : 0.f;
-
-    float bv[KK];
-    int bi[KK];
-#pragma unroll
-    for (int m = 0; m < KK; ++m) {
-        bv[m] = -INFINITY;
-        bi[m] = 0x7fffffff;
-    }
-
-    const int ntile = (N + 31) / 32;
-    for (int t = w; t < ntile; t += MW) {
-        const int c0 = t * 32;
-        const int ci = c0 + lr;
-        const bool cok = ci < N;
-        float af[KSTEPS];
-#pragma unroll
-        for (int kk = 0; kk < KSTEPS; ++kk) {
-            const int d = 2 * kk + lk;
-            af[kk] = (cok && d < D) ? xb[(int64_t)d * N + ci] : 0.f;
-        }
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-        for (int kk = 0; kk < KSTEPS; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk], bq[kk], acc, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int j = c0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-            const float sq_j = j < N ? sqb[j] : 0.f;
-            const float inner = -2.0f * acc[r];
-            const float tt = (-sq_j) - inner;
-            const float sc = j < N ? tt - sq_i : -INFINITY;
-            if (__any(sc > bv[KK - 1])) topk_insert<KK>(bv, bi, sc, j);
-        }
-    }
-#pragma unroll
-    for (int m = 0; m < KK; ++m) {
-        lval[lr][2 * w + lk][m] = bv[m];
-        lidx[lr][2 * w + lk][m] = bi[m];
-    }
-    __syncthreads();
-    // 8-way merge of the sorted sub-lists: one thread per query
-    if (threadIdx.x < MQ && q0 + (int)threadIdx.x < N) {
-        const int q = threadIdx.x;
-        int head[2 * MW];
-#pragma unroll
-        for (int u = 0; u < 2 * MW; ++u) head[u] = 0;
-        int64_t* o = idx + ((int64_t)b * N + q0 + q) * k;
-        for (int m = 0; m < k; ++m) {
-            float best = -INFINITY;
-            int bidx = 0x7fffffff, bu = 0;
-#pragma unroll
-            for (int u = 0; u < 2 * MW; ++u) {
-                const int h = head[u];
-                const float v = h < KK ? lval[q][u][h] : -INFINITY;
-                const int i2 = h < KK ? lidx[q][u][h] : 0x7fffffff;
-                if (v > best || (v == best && i2 < bidx)) {
-                    best = v;
-                    bidx = i2;
-                    bu = u;
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 2 * MW; ++u) head[u] += (u == bu) ? 1 : 0;
-            o[m] = bidx;
-        }
-    }
-}
 
 // Sorting-network variant of the 4-wave kernel (k <= 32).  With eight short lists per query nearly every score enters some
 // list, so the per-score sorted insertion (~120 instructions) runs 16 times per tile.  Here a (score, index) pair is ONE
@@ -771,10 +678,8 @@ int launch_knn_mfma(const float* x, const float* sq, int B, int D, int N, int k,
     // and for N = 2048, k = 40 (lists longer than the 32-wide merge network): queued 390-500 us, insertion 817-894 us;
     // r02: sorting network on 32-wide lists + flagged exact repair (see knn_mfma_sort_kernel): measured below.
     // So: k <= 32 -> sorting network; 32 < k <= 40 -> sorting network with 32-wide lists + repair pass of the queued kernel.
-    const char* e = getenv("HPCS_KNN_KERNEL");     // tiled|insert|queue|bq overrides the choice (A/B tests; read on every call)
-    const int force = !e ? 0 : (e[0] == 't' ? 1 : (e[0] == 'i' ? 3 : (e[0] == 'b' ? (e[1] == 'q' && e[2] == '2' ? 5 : 4) : 2)));
-    // tiled (sorting network) | insert | bq | bq2 | queue
-    const bool tiled = force == 1 || force == 3 || (force == 0 && k <= 32);
+    const int force = hpcs_tuning().knn_kernel;      // 0 auto | 1 tiled (sorting network) | 2 queue | 4 bq | 5 bq2 (A/B tests)
+    const bool tiled = force == 1 || (force == 0 && k <= 32);
     // k <= 32: the batch-queue kernel (one wave per 32 queries) once there is a wave per SIMD, the 4-wave sorting-network
     // kernel for small batches (B=8, N=500 D=63: 31 vs 50 us; B=32, N=1024: 57 vs 40 (D=3), 129 vs 95 (D=63) with two waves per
     // query tile; B=4096: 4935 vs 2585 with one)
@@ -799,11 +704,9 @@ int launch_knn_mfma(const float* x, const float* sq, int B, int D, int N, int k,
         else if (bq && KK <= 32)                                                                              \
             hipLaunchKernelGGL((knn_mfma_bq_kernel<KSTEPS, (KK <= 32 ? KK : 32), 1>), grid, dim3(64), 0, st, x, sq, D, N, k, idx, \
                                (int*)nullptr);                                                                \
-        else if (tiled && KK <= 32 && force != 3)                                                                  \
+        else if (tiled && KK <= 32)                                                                           \
             hipLaunchKernelGGL((knn_mfma_sort_kernel<KSTEPS, (KK <= 32 ? KK : 32)>), grid, dim3(MW * 64), 0, st, x, sq, D, N, k, \
                                idx, (int*)nullptr);                                                           \
-        else if (tiled)                                                                                       \
-            hipLaunchKernelGGL((knn_mfma_kernel<KSTEPS, KK>), grid, dim3(MW * 64), 0, st, x, sq, D, N, k, idx); \
         else                                                                                                  \
             hipLaunchKernelGGL((knn_mfma_queue_kernel<KSTEPS, KK, 1>), grid, dim3(64), 0, st, x, sq, D, N, k, idx, \
                                (const int*)nullptr);                                                          \

@@ -2043,21 +2043,16 @@ extern "C" int hpcs_hyphc_sampled(const float* xn, const int64_t* labels, const 
     // Workgroups are resident one per CU (128 KB of LDS), so the grid runs in rounds of n_cu workgroups: pick the
     // segment length (multiple of 8) that wastes the least of the last round; ties go to the longer segment, which
     // amortises the positive table's zero/flush best.  The triplet stream depends on (seed, t) only, not on this.
-    static int n_cu = 0;
-    static int seg_env = -1;
-    // kernel variant: 4 (default, r03: four triplets per group and batch, rows kept in registers) | 8 (r02: eight, rows
-    // gathered twice); HPCS_SAMPLED_V, read on every call (A/B tests)
-    const char* ve = getenv("HPCS_SAMPLED_V");
-    // (E = 64 stays on the r02 kernel: eight rows of 8 registers spill at the 128-register cap)
-    const int variant = ((ve && ve[0] == '8') || T >= (int64_t)0x7F000000 || E == 64) ? 8 : 4;
-    if (n_cu == 0) {
+    static const int n_cu = [] {
         int dev = 0, v = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
             v = 256;
-        n_cu = v;
-        const char* e = getenv("HPCS_SAMPLED_SEG");          // tuning override (multiple of 8 in [8, 256])
-        seg_env = e ? atoi(e) : 0;
-    }
+        return v;
+    }();
+    // kernel variant: 4 (default, r03: four triplets per group and batch, rows kept in registers) | 8 (r02: eight, rows
+    // gathered twice; E = 64 stays on it: eight rows of 8 registers spill at the 128-register cap); tuning table
+    const int variant = (hpcs_tuning().sampled_v == 8 || T >= (int64_t)0x7F000000 || E == 64) ? 8 : 4;
+    const int seg_env = hpcs_tuning().sampled_seg;                   // override (multiple of 8 in [8, 256]); 0: chosen below
     int seg_len = SB_SEG_MAX;
     if (seg_env >= 8 && seg_env <= SB_SEG_MAX && seg_env % 8 == 0) {
         seg_len = seg_env;
@@ -2091,8 +2086,8 @@ extern "C" int hpcs_hyphc_sampled(const float* xn, const int64_t* labels, const 
             hipDeviceGetAttribute(&cap, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || cap <= 0)
             cap = 64 * 1024;
         const size_t room = (size_t)cap > 4096 ? (size_t)cap - 4096 : (size_t)cap;      // static LDS of the kernel + slack
-        const char* e = getenv("HPCS_SAMPLED_LDS_KB");
-        size_t want = (size_t)((e && atoi(e) > 0) ? atoi(e) : 156) * 1024;
+        const int kb = hpcs_tuning().sampled_lds_kb;
+        size_t want = (size_t)(kb > 0 ? kb : 156) * 1024;
         return want < room ? want : room;
     }();
     const size_t row_bytes = (size_t)(E + 8) * sizeof(float);

@@ -1939,7 +1939,7 @@ __global__ __launch_bounds__(INV_T) void edge_grad_reduce_slab_kernel(const floa
 // N / slabs source points owns exactly INV_MAXL edges (N <= 2048), allowed only when the caller handles slabs.
 bool inv_graph_build(const int64_t* idx, int B, int N, int k, bool vec, void* ws, size_t ws_bytes, hipStream_t st, InvGraph* out,
                      int* slabs = nullptr, bool launch = true) {
-    static const bool off = getenv("HPCS_EDGE_BWD_ATOMIC") != nullptr;
+    const bool off = hpcs_tuning().edge_bwd_atomic != 0;
     const int64_t L = (int64_t)N * k;
     if (off || !vec || (L % 4) != 0) return false;
     int S = 1;

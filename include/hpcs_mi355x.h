@@ -478,6 +478,10 @@ int hpcs_debug_watch(const void* watched, const void* shadow, int nbytes, int se
  * 3 host, 4 child graph, 5 empty, ...), child graphs included.  Returns the node total or a negative status.  The step
  * driver refuses a capture holding memset nodes (their arguments do not survive a second graph on this runtime). */
 int hpcs_debug_graph_census(void* graph, int64_t* counts16);
+/* Tests only: replace one value of the library's tuning table (csrc/common.h HpcsTuning: the HPCS_* switches, read from the
+ * environment once at first use and immutable afterwards).  name = the environment variable's name; value = its integer
+ * code (HPCS_KNN_KERNEL: 0 auto, 1 tiled, 2 queue, 4 bq, 5 bq2). */
+int hpcs_debug_set_tuning(const char* name, int value);
 
 #ifdef __cplusplus
 }

@@ -18,3 +18,21 @@ def pytest_configure(config):
 def golden():
     """Outputs of the reference captured by tests/golden/make_golden.py."""
     return dict(np.load(os.path.join(ROOT, "tests", "golden", "reference_vectors.npz")))
+
+
+@pytest.fixture
+def tuning():
+    """Setter for the library's tuning table (hpcs_debug_set_tuning: the HPCS_* switches are read from the environment once,
+    so tests that A/B a kernel variant replace the value in place); the touched entries are put back afterwards."""
+    from hpcs_amd import _lib
+    defaults = {"HPCS_KNN_KERNEL": 0, "HPCS_SAMPLED_V": 4, "HPCS_SAMPLED_SEG": 0, "HPCS_EDGE_BWD_ATOMIC": 0}
+    touched = []
+
+    def set_(name, value):
+        if name not in defaults:
+            raise KeyError(name)
+        _lib.set_tuning(name, value)
+        touched.append(name)
+    yield set_
+    for name in touched:
+        _lib.set_tuning(name, defaults[name])

@@ -36,13 +36,13 @@ def test_knn_bit_exact(B, D, N, k, seed):
     assert torch.equal(got, want)
 
 
-@pytest.mark.parametrize("kernel", ["tiled", "insert", "queue", "bq", "bq2"])
-def test_knn_both_mfma_kernels_bit_exact(kernel, monkeypatch):
-    """The MFMA selection kernels (interleaved 4-wave tiles with a sorting network or per-score insertion / one wave with
+@pytest.mark.parametrize("kernel", ["tiled", "queue", "bq", "bq2"])
+def test_knn_both_mfma_kernels_bit_exact(kernel, tuning):
+    """The MFMA selection kernels (interleaved 4-wave tiles with a sorting network / one wave with
     per-lane queues / one wave with a stack of pending candidates merged 16 at a time) are chosen by problem size and k;
     each must reproduce the oracle on every shape, duplicates included ("bq" serves k <= 32: larger k falls through to the
     queued kernel; "bq2" = two waves per query tile, and for k = 33..40 32-wide lists with the flagged repair pass)."""
-    monkeypatch.setenv("HPCS_KNN_KERNEL", kernel)
+    tuning("HPCS_KNN_KERNEL", _lib.KNN_KERNEL_CODES[kernel])
     for B, D, N, k, seed in [(2, 3, 256, 10, 31), (3, 3, 1024, 20, 32), (2, 63, 512, 20, 33), (1, 63, 2048, 40, 34),
                              (2, 3, 100, 7, 35), (1, 3, 64, 33, 36)]:
         x = det_cloud(B, N, seed) if D == 3 else det_normalish((B, D, N), seed)

@@ -236,12 +236,12 @@ def test_hierarchical_cosface_loss_and_grads():
 
 
 @pytest.mark.parametrize("variant,E", [("4", 32), ("8", 32), ("4", 16), ("4", 64)])
-def test_hyphc_sampled_in_kernel(variant, E, monkeypatch):
+def test_hyphc_sampled_in_kernel(variant, E, tuning):
     """The training-path kernel (triplets generated in-kernel, LDS positive table) against the array-based kernels
     run on the very triplets it generated, plus validity / balance of those triplets.  variant: HPCS_SAMPLED_V -- "4" = the
     r03 kernel (four triplets per group and batch, rows kept in registers; E = 64 falls back to "8"), "8" = the r02 kernel."""
     from hpcs_amd.loss.ultrametric_loss import MetricHyperbolicLoss, HypHCFn, L2RowsFn
-    monkeypatch.setenv("HPCS_SAMPLED_V", variant)
+    tuning("HPCS_SAMPLED_V", int(variant))
     M, C = 6000, 7
     x = OH.expmap0(det_normalish((M, E), 61) * 0.5)
     lab = torch.cat([det_int((M - 900,), 62, C - 1), torch.full((900,), C - 1)])        # one large class

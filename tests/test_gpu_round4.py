@@ -61,11 +61,11 @@ def chi2_band(stat, dof, sigmas=6.0):
     return abs(stat - dof) <= sigmas * math.sqrt(2.0 * dof)
 
 
-def check_sampled_against_oracle(E, M, lab, t_per_anchor, scale, oracle_device, gathered32, variant=None, monkeypatch=None,
+def check_sampled_against_oracle(E, M, lab, t_per_anchor, scale, oracle_device, gathered32, variant=None, tuning=None,
                                  chi2=False):
     from hpcs_amd.loss.ultrametric_loss import MetricHyperbolicLoss
     if variant is not None:
-        monkeypatch.setenv("HPCS_SAMPLED_V", variant)
+        tuning("HPCS_SAMPLED_V", int(variant))
     C = int(lab.max()) + 1
     x = OH.expmap0(det_normalish((M, E), 61 + E) * 0.5)
     crit = MetricHyperbolicLoss(t_per_anchor=t_per_anchor, fraction=1.2, scale=torch.nn.Parameter(torch.tensor([scale])),
@@ -146,21 +146,21 @@ def check_sampled_against_oracle(E, M, lab, t_per_anchor, scale, oracle_device, 
 
 
 @pytest.mark.parametrize("variant,E,scale", [("4", 32, 0.03), ("4", 32, 1e-3), ("8", 32, 0.03), ("4", 16, 0.03), ("4", 64, 0.03)])
-def test_sampled_hyphc_kernel_against_the_fp64_oracle(variant, E, scale, monkeypatch):
+def test_sampled_hyphc_kernel_against_the_fp64_oracle(variant, E, scale, tuning):
     """M = 6000 with one class of 1500 rows (beyond the LDS positive table at every E: overflow rows and finished anchors
     leave through the ring), oracle on the host."""
     lab = one_big_class(6000, 7, 1500, 62)
-    check_sampled_against_oracle(E, 6000, lab, 9, scale, "cpu", gathered32=True, variant=variant, monkeypatch=monkeypatch,
+    check_sampled_against_oracle(E, 6000, lab, 9, scale, "cpu", gathered32=True, variant=variant, tuning=tuning,
                                  chi2=(variant == "4" and E == 32 and scale == 0.03))
 
 
 @pytest.mark.parametrize("variant", ["4", "8"])
-def test_sampled_hyphc_kernel_at_the_bench_size(variant, monkeypatch):
+def test_sampled_hyphc_kernel_at_the_bench_size(variant, tuning):
     """The benchmark's own loss workload: M = 32768, the Voronoi labels of bench.synthetic_batch (C = 50, four classes of
     2600-3800 points), t_per_anchor = 50, fraction 1.2 -> 16.9 M sampled triplets; scale 1e-3 (base_hyp_hc.py:62)."""
     lab = bench_labels()
     r = check_sampled_against_oracle(32, 32768, lab, 50, 1e-3, dev, gathered32=False, variant=variant,
-                                     monkeypatch=monkeypatch, chi2=(variant == "4"))
+                                     tuning=tuning, chi2=(variant == "4"))
     assert r["T"] > 16_000_000
 
 
