@@ -24,6 +24,7 @@ struct HpcsTuning {
     int nt_big_wg;         // HPCS_NT_BIG_WG      workgroups of that kernel (512 = two per CU)
     int gemm_vecstore;     // HPCS_GEMM_VECSTORE  16-byte epilogue stores through LDS (1)
     int gemm_tn_guarded;   // HPCS_GEMM_TN_GUARDED bounds-tested operand loader (0)
+    int gemm_x3;           // HPCS_GEMM_X3        large dense GEMMs as six bf16-piece products on the bf16 MFMA, fp32 accurate (1)
     int knn_kernel;        // HPCS_KNN_KERNEL     0 auto | 1 tiled (sorting network) | 2 queue | 4 bq | 5 bq2
     int sampled_v;         // HPCS_SAMPLED_V      sampled HypHC kernel: 4 (r03 form) | 8 (r02 form, also serves E = 64)
     int sampled_seg;       // HPCS_SAMPLED_SEG    triplets per 8-lane group (0 = chosen per launch)

@@ -122,6 +122,7 @@ static HpcsTuning read_tuning() {
     t.nt_big_wg = env_int("HPCS_NT_BIG_WG", 512);
     t.gemm_vecstore = env_int("HPCS_GEMM_VECSTORE", 1) != 0;
     t.gemm_tn_guarded = env_int("HPCS_GEMM_TN_GUARDED", 0) != 0;
+    t.gemm_x3 = env_int("HPCS_GEMM_X3", 1) != 0;
     const char* k = getenv("HPCS_KNN_KERNEL");
     t.knn_kernel = !k || !*k ? 0 : (k[0] == 't' ? 1 : (k[0] == 'b' ? (k[1] == 'q' && k[2] == '2' ? 5 : 4) : 2));
     t.sampled_v = env_int("HPCS_SAMPLED_V", 4) == 8 ? 8 : 4;
@@ -143,7 +144,7 @@ extern "C" int hpcs_debug_set_tuning(const char* name, int value) {
     HpcsTuning& t = tuning_storage();
     struct { const char* n; int* p; } tab[] = {
         {"HPCS_NT_WG_TARGET", &t.nt_wg_target}, {"HPCS_NT_BIG_MIN", &t.nt_big_min}, {"HPCS_NT_BIG_WG", &t.nt_big_wg},
-        {"HPCS_GEMM_VECSTORE", &t.gemm_vecstore}, {"HPCS_GEMM_TN_GUARDED", &t.gemm_tn_guarded}, {"HPCS_KNN_KERNEL", &t.knn_kernel},
+        {"HPCS_GEMM_VECSTORE", &t.gemm_vecstore}, {"HPCS_GEMM_TN_GUARDED", &t.gemm_tn_guarded}, {"HPCS_GEMM_X3", &t.gemm_x3}, {"HPCS_KNN_KERNEL", &t.knn_kernel},
         {"HPCS_SAMPLED_V", &t.sampled_v}, {"HPCS_SAMPLED_SEG", &t.sampled_seg}, {"HPCS_SAMPLED_LDS_KB", &t.sampled_lds_kb},
         {"HPCS_EDGE_BWD_ATOMIC", &t.edge_bwd_atomic}};
     for (auto& e : tab)

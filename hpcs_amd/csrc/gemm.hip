@@ -1197,6 +1197,12 @@ extern "C" int hpcs_gemm_tn(const float* At, int lda, const float* Bm, int ldb, 
     hipLaunchKernelGGL((gemm_tn_kernel<BM_, 128, 16, WM_, WN_, FAST_>), dim3((unsigned)total), dim3(256), 0, st, At, lda, Bm,     \
                        ldb, strideB_o, strideB_i, C, ldc, strideC_o, strideC_i, M, Nc, K, n_inner, rowbias, accumulate, tm, tn,  \
                        (unsigned)total, vecA, vecB, vecC)
+    // The large dense layers (M > 64) take the bf16x3 kernel (csrc/gemm_x3.hip): fp32-accurate products on the bf16 matrix
+    // cores, 1.4-1.6x the fma-chain kernel below; HPCS_GEMM_X3=0 keeps the fma chain (A/B, and the form whose k-ordered
+    // rounding sequence the kNN and the graph-operand GEMM are pinned to -- those never come here).
+    if (M > 64 && hpcs_tuning().gemm_x3)
+        return hpcs_gemm_tn_x3(At, lda, Bm, ldb, strideB_o, strideB_i, C, ldc, strideC_o, strideC_i, M, Nc, K, n_outer, n_inner,
+                               rowbias, accumulate, stream);
     const int BMsel = M > 64 ? 128 : 64;
     const int tm = hpcs_cdiv(M, BMsel), tn = hpcs_cdiv(Nc, 128);
     const long total = (long)tm * tn * nb;

@@ -70,6 +70,13 @@ int hpcs_edge_gather_bwd(const float* gout, const int64_t* idx, int B, int C, in
 int hpcs_gemm_tn(const float* At, int lda, const float* Bm, int ldb, int64_t strideB_o, int64_t strideB_i,
                  float* C, int ldc, int64_t strideC_o, int64_t strideC_i, int M, int Nc, int K, int n_outer,
                  int n_inner, const float* rowbias, int accumulate, hpcs_stream_t stream);
+/* hpcs_gemm_tn_x3: the same product with the same arguments, evaluated on the BF16 matrix cores at fp32 accuracy: every
+ * fp32 operand splits exactly into three bf16 pieces and six piece products (exact in fp32, accumulated in fp32 by the MFMA)
+ * carry the product to 2^-23 |a||b| (csrc/gemm_x3.hip).  Not bit-identical to the fma chain of hpcs_gemm_tn -- as close to
+ * the exact product (tests).  Used for the large dense layers (M > 64); kNN and the EdgeConv mixes keep the fma chain. */
+int hpcs_gemm_tn_x3(const float* At, int lda, const float* Bm, int ldb, int64_t strideB_o, int64_t strideB_i,
+                    float* C, int ldc, int64_t strideC_o, int64_t strideC_i, int M, int Nc, int K, int n_outer,
+                    int n_inner, const float* rowbias, int accumulate, hpcs_stream_t stream);
 /* prep_weights: W = [W1 (M1 x K, row stride ld1); W2 (M2 x K, row stride ld2, optional)] -> both GEMM operands in one
  * launch: At [K, lda >= M] = W^T and Wp [M, ldp >= K] = W, zero padded (lda, ldp multiples of 4 for 16-byte loads). */
 int hpcs_prep_weights(const float* W1, int ld1, int M1, const float* W2, int ld2, int M2, int K, float* At, int lda,

@@ -25,7 +25,7 @@ def tuning():
     """Setter for the library's tuning table (hpcs_debug_set_tuning: the HPCS_* switches are read from the environment once,
     so tests that A/B a kernel variant replace the value in place); the touched entries are put back afterwards."""
     from hpcs_amd import _lib
-    defaults = {"HPCS_KNN_KERNEL": 0, "HPCS_SAMPLED_V": 4, "HPCS_SAMPLED_SEG": 0, "HPCS_EDGE_BWD_ATOMIC": 0}
+    defaults = {"HPCS_KNN_KERNEL": 0, "HPCS_SAMPLED_V": 4, "HPCS_SAMPLED_SEG": 0, "HPCS_EDGE_BWD_ATOMIC": 0, "HPCS_GEMM_X3": 1}
     touched = []
 
     def set_(name, value):
