@@ -14,6 +14,10 @@
 
 #include "common.h"
 
+int hpcs_x3_nt_big_launch(const float* G, int ldg, int64_t sGo, int64_t sGi, const float* X, int ldx, int64_t sXo, int64_t sXi, int M,
+                          int Kx, int Nc, int n_inner, int n_batch, int nsplit, float* part, int tilesM, int tilesK, int vecG, int vecX,
+                          long blocks, hipStream_t st);      // csrc/gemm_x3.hip
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -1314,7 +1318,12 @@ static int gemm_nt_impl(const float* G, int ldg, int64_t strideG_o, int64_t stri
         hipLaunchKernelGGL(gemm_nt_edge_kernel, dim3((unsigned)blocks), dim3(256), 0, st, G, ldg, strideG_o, strideG_i, X, ldx,
                            strideX_o, strideX_i, M, Kx, Nc, n_inner, nb, p.chunk, p.units_per_batch, p.nsplit, (float*)ws, vecG,
                            vecX, fuse);
-    else if (p.tile == 128)
+    else if (p.tile == 128 && hpcs_tuning().gemm_x3) {
+        // the same tile and work split on the bf16 matrix cores at fp32 accuracy (csrc/gemm_x3.hip)
+        if (const int rc = hpcs_x3_nt_big_launch(G, ldg, strideG_o, strideG_i, X, ldx, strideX_o, strideX_i, M, Kx, Nc, n_inner, nb,
+                                                 p.nsplit, (float*)ws, p.tilesM, p.tilesK, vecG, vecX, blocks, st))
+            return rc;
+    } else if (p.tile == 128)
         hipLaunchKernelGGL(gemm_nt_big_kernel<false>, dim3((unsigned)blocks), dim3(256), nb_lds_bytes(), st, G, ldg, strideG_o, strideG_i, X,
                            ldx, strideX_o, strideX_i, M, Kx, Nc, n_inner, nb, p.chunk, p.units_per_batch, p.nsplit, (float*)ws,
                            p.tilesM, p.tilesK, vecG, vecX, fuse);

@@ -180,7 +180,137 @@ __global__ __launch_bounds__(256, X3_WPS) void gemm_tn_x3_kernel(
         }
 }
 
+// ---- weight gradients of the large layers: dW (M x Kx) = sum_b G[b] (M x Nc) X[b]^T (Kx x Nc), split over the column steps.
+// Both operands have the contraction index contiguous in memory, so the loader thread takes eight consecutive columns of
+// one row (two 16-byte loads), splits them and writes the three [row][k8] pieces; everything else is the tile above.  Same
+// work split as gemm_nt_big_kernel (csrc/gemm.hip): ONE list of 16-column steps over all batches cut into equal ranges, plain
+// partials [split][M][Kx] summed by split_reduce.
+__device__ __forceinline__ void ld8_guard(const float* __restrict__ rowp, int col, int ncols, bool rowok, bool vec, float (&v)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    if (!rowok) return;
+    if (vec && col + 7 < ncols) {
+        const float4 a = *reinterpret_cast<const float4*>(rowp + col), b = *reinterpret_cast<const float4*>(rowp + col + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (col + j < ncols) v[j] = rowp[col + j];
+}
+
+__global__ __launch_bounds__(256, X3_WPS) void gemm_nt_big_x3_kernel(
+    const float* __restrict__ G, int ldg, int64_t sGo, int64_t sGi, const float* __restrict__ X, int ldx, int64_t sXo,
+    int64_t sXi, int M, int Kx, int Nc, int n_inner, int n_batch, int nsplit, float* __restrict__ part, int tilesM, int tilesK,
+    int vecG, int vecX) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char x3_lds[];
+    const unsigned bid = hpcs_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = bid % (tilesM * tilesK);
+    const int split = bid / (tilesM * tilesK);
+    const int m0 = (tile % tilesM) * 128, x0 = (tile / tilesM) * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 31, lk = lane >> 5;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int spb = (Nc + X3_BK - 1) / X3_BK;
+    const int64_t T = (int64_t)n_batch * spb;
+    int64_t g = (int64_t)split * T / nsplit;
+    const int64_t g_end = (int64_t)(split + 1) * T / nsplit;
+    const int lrow = tid >> 1, lh = tid & 1;               // loader: thread = (row, 8-column half of the step)
+    float rg[8], rx[8];
+    auto gload = [&](int64_t gs) {
+        const int batch = (int)(gs / spb);
+        const int c0 = (int)(gs % spb) * X3_BK + 8 * lh;
+        const int bo = batch / n_inner, bi = batch % n_inner;
+        ld8_guard(G + bo * sGo + bi * sGi + (int64_t)(m0 + lrow) * ldg, c0, Nc, m0 + lrow < M, vecG, rg);
+        ld8_guard(X + bo * sXo + bi * sXi + (int64_t)(x0 + lrow) * ldx, c0, Nc, x0 + lrow < Kx, vecX, rx);
+    };
+    auto lstore = [&]() {
+        u32x4 p1, p2, p3;
+        unsigned char* base = x3_lds + lrow * X3_PITCH + lh * 16;
+        split8(rg, p1, p2, p3);
+        *reinterpret_cast<u32x4*>(base) = p1;
+        *reinterpret_cast<u32x4*>(base + X3_PIECE) = p2;
+        *reinterpret_cast<u32x4*>(base + 2 * X3_PIECE) = p3;
+        split8(rx, p1, p2, p3);
+        *reinterpret_cast<u32x4*>(base + X3_OPER) = p1;
+        *reinterpret_cast<u32x4*>(base + X3_OPER + X3_PIECE) = p2;
+        *reinterpret_cast<u32x4*>(base + X3_OPER + 2 * X3_PIECE) = p3;
+    };
+    bool live[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) live[i][j] = (m0 + wm * 64 + i * 32 < M) && (x0 + wn * 64 + j * 32 < Kx);
+    const unsigned char* sa = x3_lds + (wm * 64 + lr) * X3_PITCH + lk * 16;
+    const unsigned char* sb = x3_lds + X3_OPER + (wn * 64 + lr) * X3_PITCH + lk * 16;
+    if (g < g_end) {
+        gload(g);
+        lstore();
+    }
+    __syncthreads();
+    for (; g < g_end; ++g) {
+        const bool have_next = g + 1 < g_end;
+        if (have_next) gload(g + 1);
+        bf16x8 a[2][3], b[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                a[i][p] = *reinterpret_cast<const bf16x8*>(sa + p * X3_PIECE + i * 32 * X3_PITCH);
+                b[i][p] = *reinterpret_cast<const bf16x8*>(sb + p * X3_PIECE + i * 32 * X3_PITCH);
+            }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                if (live[i][j]) {
+                    f32x16 c = acc[i][j];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);
+                    acc[i][j] = c;
+                }
+        __syncthreads();                                       // everybody has read its fragments
+        if (have_next) lstore();
+        __syncthreads();
+    }
+    float* P = part + (int64_t)split * M * Kx;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = x0 + wn * 64 + j * 32 + lr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (row < M && col < Kx) P[(int64_t)row * Kx + col] = acc[i][j][r];
+            }
+        }
+}
+
 }  // namespace
+
+// launcher for csrc/gemm.hip's weight-gradient dispatch (plain partials; the caller runs its split_reduce launches)
+int hpcs_x3_nt_big_launch(const float* G, int ldg, int64_t sGo, int64_t sGi, const float* X, int ldx, int64_t sXo, int64_t sXi, int M,
+                          int Kx, int Nc, int n_inner, int n_batch, int nsplit, float* part, int tilesM, int tilesK, int vecG, int vecX,
+                          long blocks, hipStream_t st) {
+    static const bool attr_ok = hipFuncSetAttribute((const void*)gemm_nt_big_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                    X3_STAGE) == hipSuccess;
+    if (!attr_ok) return HPCS_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(gemm_nt_big_x3_kernel, dim3((unsigned)blocks), dim3(256), X3_STAGE, st, G, ldg, sGo, sGi, X, ldx, sXo, sXi, M, Kx,
+                       Nc, n_inner, n_batch, nsplit, part, tilesM, tilesK, vecG, vecX);
+    return HPCS_OK;
+}
 
 extern "C" int hpcs_gemm_tn_x3(const float* At, int lda, const float* Bm, int ldb, int64_t strideB_o, int64_t strideB_i, float* C,
                                int ldc, int64_t strideC_o, int64_t strideC_i, int M, int Nc, int K, int n_outer, int n_inner,
