@@ -30,11 +30,6 @@ constexpr int X3_PITCH = 48;                        // bytes per [row][16 k] LDS
 constexpr int X3_PIECE = X3_BM * X3_PITCH;          // one split level of one operand tile: 6 KB
 constexpr int X3_OPER = 3 * X3_PIECE;               // 18 KB
 constexpr int X3_STAGE = 2 * X3_OPER;               // A + B: 36 KB
-#ifndef X3_DB
-#define X3_DB 0                                      // 1: double-buffered LDS (72 KB, two workgroups per CU, one barrier per step)
-#endif
-constexpr int X3_NBUF = X3_DB ? 2 : 1;
-constexpr int X3_WPS = X3_DB ? 2 : 3;               // waves per SIMD the register budget is set for
 
 // two fp32 -> packed pair of bf16 (round to nearest even), and back
 __device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
@@ -61,7 +56,91 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4& p1, u32x4& p2
     }
 }
 
-__global__ __launch_bounds__(256, X3_WPS) void gemm_tn_x3_kernel(
+// The six piece products of one 32 x 32 tile, smallest terms first
+#define X3_MMA6(c, a, b)                                                        \
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);        \
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);        \
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);        \
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);        \
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);        \
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
+
+// Software pipeline of one workgroup (single LDS stage, two register sets for the raw operands):
+//   step kt:  request the raw operands of step kt+2 | read the fragments of step kt from LDS | the 24 MFMAs of step kt
+//             INTERLEAVED with the VALU split of step kt+1's raw operands (the matrix pipe runs under the ~100 split
+//             instructions instead of after them: sched_group_barrier) | barrier | write the split pieces | barrier.
+template <bool FULL>
+__device__ __forceinline__ void x3_tn_tile(const float* __restrict__ Ag, int lda, const float* __restrict__ Bg, int ldb, int K,
+                                           int lh, unsigned char* wbase, const unsigned char* sa, const unsigned char* sb,
+                                           const bool (&live)[2][2], f32x16 (&acc)[2][2]) {
+    float ra[8], rb[8];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = min(k0 + 8 * lh + j, K - 1);                     // clamped; zeroed before the split
+            ra[j] = Ag[(int64_t)k * lda];
+            rb[j] = Bg[(int64_t)k * ldb];
+        }
+    };
+    auto zero_tail = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool in = k0 + 8 * lh + j < K;
+            ra[j] = in ? ra[j] : 0.f;
+            rb[j] = in ? rb[j] : 0.f;
+        }
+    };
+    auto lwrite = [&](const u32x4 (&pa)[3], const u32x4 (&pb)[3]) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            *reinterpret_cast<u32x4*>(wbase + p * X3_PIECE) = pa[p];
+            *reinterpret_cast<u32x4*>(wbase + X3_OPER + p * X3_PIECE) = pb[p];
+        }
+    };
+    const int nk = (K + X3_BK - 1) / X3_BK;
+    u32x4 pa[3], pb[3];
+    gload(0);
+    zero_tail(0);
+    split8(ra, pa[0], pa[1], pa[2]);
+    split8(rb, pb[0], pb[1], pb[2]);
+    if (nk > 1) gload(X3_BK);
+    lwrite(pa, pb);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        // (ra, rb) hold the raw operands of step kt+1 (requested one step ago); after their split the same registers take
+        // the request for step kt+2, which has the barriers, the piece stores and the first MFMAs of the next step to land
+        bf16x8 a[2][3], b[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                a[i][p] = *reinterpret_cast<const bf16x8*>(sa + p * X3_PIECE + i * 32 * X3_PITCH);
+                b[i][p] = *reinterpret_cast<const bf16x8*>(sb + p * X3_PIECE + i * 32 * X3_PITCH);
+            }
+        const bool have1 = kt + 1 < nk;
+        if (FULL) {
+            X3_MMA6(acc[0][0], a[0], b[0]) X3_MMA6(acc[0][1], a[0], b[1])
+            zero_tail((kt + 1) * X3_BK);
+            split8(ra, pa[0], pa[1], pa[2]);
+            X3_MMA6(acc[1][0], a[1], b[0]) X3_MMA6(acc[1][1], a[1], b[1])
+            split8(rb, pb[0], pb[1], pb[2]);
+        } else {
+            if (live[0][0]) { X3_MMA6(acc[0][0], a[0], b[0]) }
+            if (live[0][1]) { X3_MMA6(acc[0][1], a[0], b[1]) }
+            if (live[1][0]) { X3_MMA6(acc[1][0], a[1], b[0]) }
+            if (live[1][1]) { X3_MMA6(acc[1][1], a[1], b[1]) }
+            zero_tail((kt + 1) * X3_BK);
+            split8(ra, pa[0], pa[1], pa[2]);
+            split8(rb, pb[0], pb[1], pb[2]);
+        }
+        if (kt + 2 < nk) gload((kt + 2) * X3_BK);
+        __syncthreads();                                       // everybody has read its fragments of step kt
+        if (have1) lwrite(pa, pb);
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(
     const float* __restrict__ At, int lda, const float* __restrict__ Bm, int ldb, int64_t sBo, int64_t sBi,
     float* __restrict__ C, int ldc, int64_t sCo, int64_t sCi, int M, int Nc, int K, int n_inner,
     const float* __restrict__ rowbias, int accumulate, int tilesM, int tilesN, unsigned total) {
@@ -83,30 +162,6 @@ __global__ __launch_bounds__(256, X3_WPS) void gemm_tn_x3_kernel(
     const int lrow = tid & 127, lh = tid >> 7;
     const float* Ag = At + min(m0 + lrow, M - 1);
     const float* Bg = Bp + min(n0 + lrow, Nc - 1);
-    float ra[8], rb[8];
-    auto gload = [&](int k0) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = min(k0 + 8 * lh + j, K - 1);                     // clamped; zeroed in lstore
-            ra[j] = Ag[(int64_t)k * lda];
-            rb[j] = Bg[(int64_t)k * ldb];
-        }
-    };
-    auto lstore = [&](int buf, int k0) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (k0 + 8 * lh + j >= K) { ra[j] = 0.f; rb[j] = 0.f; }
-        u32x4 p1, p2, p3;
-        unsigned char* base = x3_lds + buf * X3_STAGE + lrow * X3_PITCH + lh * 16;
-        split8(ra, p1, p2, p3);
-        *reinterpret_cast<u32x4*>(base) = p1;
-        *reinterpret_cast<u32x4*>(base + X3_PIECE) = p2;
-        *reinterpret_cast<u32x4*>(base + 2 * X3_PIECE) = p3;
-        split8(rb, p1, p2, p3);
-        *reinterpret_cast<u32x4*>(base + X3_OPER) = p1;
-        *reinterpret_cast<u32x4*>(base + X3_OPER + X3_PIECE) = p2;
-        *reinterpret_cast<u32x4*>(base + X3_OPER + 2 * X3_PIECE) = p3;
-    };
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -116,65 +171,65 @@ __global__ __launch_bounds__(256, X3_WPS) void gemm_tn_x3_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     bool live[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) live[i][j] = (m0 + wm * 64 + i * 32 < M) && (n0 + wn * 64 + j * 32 < Nc);
-
-    const int lr = lane & 31, lk = lane >> 5;
-    const int fa = (wm * 64 + lr) * X3_PITCH + lk * 16;          // fragment offsets inside a piece
-    const int fb = (wn * 64 + lr) * X3_PITCH + lk * 16;
-    const int nk = (K + X3_BK - 1) / X3_BK;
-    gload(0);
-    lstore(0, 0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = X3_DB ? (kt & 1) : 0;
-        if (kt + 1 < nk) gload((kt + 1) * X3_BK);
-        const unsigned char* sa = x3_lds + buf * X3_STAGE + fa;
-        const unsigned char* sb = sa - fa + X3_OPER + fb;
-        bf16x8 a[2][3], b[2][3];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                a[i][p] = *reinterpret_cast<const bf16x8*>(sa + p * X3_PIECE + i * 32 * X3_PITCH);
-                b[i][p] = *reinterpret_cast<const bf16x8*>(sb + p * X3_PIECE + i * 32 * X3_PITCH);
-            }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                if (live[i][j]) {
-                    // smallest terms first: a3 b1 + a2 b2 + a1 b3, then a2 b1 + a1 b2, then a1 b1
-                    f32x16 c = acc[i][j];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);
-                    acc[i][j] = c;
-                }
-        if (!X3_DB) __syncthreads();                          // single stage: everybody has read its fragments
-        if (kt + 1 < nk) lstore(X3_DB ? (buf ^ 1) : 0, (kt + 1) * X3_BK);
-        __syncthreads();
-    }
-    // ---- epilogue: D layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    bool all_live = true;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 64 + j * 32 + lr;
+            live[i][j] = (m0 + wm * 64 + i * 32 < M) && (n0 + wn * 64 + j * 32 < Nc);
+            all_live = all_live && live[i][j];
+        }
+    const int lr = lane & 31, lk = lane >> 5;
+    unsigned char* wbase = x3_lds + lrow * X3_PITCH + lh * 16;
+    const unsigned char* sa = x3_lds + (wm * 64 + lr) * X3_PITCH + lk * 16;
+    const unsigned char* sb = x3_lds + X3_OPER + (wn * 64 + lr) * X3_PITCH + lk * 16;
+    // (the branch is per wave; both bodies hold the same barriers)
+    if (all_live) x3_tn_tile<true>(Ag, lda, Bg, ldb, K, lh, wbase, sa, sb, live, acc);
+    else x3_tn_tile<false>(Ag, lda, Bg, ldb, K, lh, wbase, sa, sb, live, acc);
+    // ---- epilogue: D layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).  Through a wave-private LDS patch
+    // (the operand stage is dead after the loop's last barrier) every lane owns 4 CONSECUTIVE columns and the tile leaves as
+    // 16-byte stores, eight 128-byte row segments per instruction (vn1's forward writes 268 MB), as in csrc/gemm.hip.
+    const bool vecC = (ldc % 4 == 0) && (sCo % 4 == 0) && (sCi % 4 == 0) && ((((uintptr_t)C) & 15u) == 0) && (Nc % 4 == 0);
+    constexpr int PP = 36;
+    float* patch = reinterpret_cast<float*>(x3_lds) + wave * (32 * PP);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                if (row < M && col < Nc) {
-                    float v = acc[i][j][r];
-                    if (bias) v += bias[row];
-                    float* dst = Cp + (int64_t)row * ldc + col;
-                    if (accumulate) v += *dst;
-                    *dst = v;
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row0 = m0 + wm * 64 + i * 32, col0 = n0 + wn * 64 + j * 32;
+            if (row0 >= M || col0 >= Nc) continue;               // wave-uniform
+            if (vecC) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * lk) * PP + lr] = acc[i][j][r];
+                __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0); the patch is wave-private: no barrier
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int rr = it * 8 + (lane >> 3), c4 = (lane & 7) * 4;
+                    const int row = row0 + rr, col = col0 + c4;
+                    if (row < M && col < Nc) {
+                        float4 v = *reinterpret_cast<const float4*>(patch + rr * PP + c4);
+                        if (bias) { const float bb = bias[row]; v.x += bb; v.y += bb; v.z += bb; v.w += bb; }
+                        float* dst = Cp + (int64_t)row * ldc + col;
+                        if (accumulate) {
+                            const float4 o = *reinterpret_cast<const float4*>(dst);
+                            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                        }
+                        *reinterpret_cast<float4*>(dst) = v;
+                    }
+                }
+                __builtin_amdgcn_s_waitcnt(0xC07F);              // the reads are done before the next tile overwrites
+            } else {
+                const int col = col0 + lr;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    if (row < M && col < Nc) {
+                        float v = acc[i][j][r];
+                        if (bias) v += bias[row];
+                        float* dst = Cp + (int64_t)row * ldc + col;
+                        if (accumulate) v += *dst;
+                        *dst = v;
+                    }
                 }
             }
         }
@@ -199,7 +254,10 @@ __device__ __forceinline__ void ld8_guard(const float* __restrict__ rowp, int co
         if (col + j < ncols) v[j] = rowp[col + j];
 }
 
-__global__ __launch_bounds__(256, X3_WPS) void gemm_nt_big_x3_kernel(
+// FAST: 16-byte loadable operands and Nc % 16 == 0 (every shape of the step): straight-line loads from clamped rows (a row
+// beyond the matrix reads the last row and is zeroed by a select), so that the split interleaves with the MFMAs.
+template <bool FAST>
+__global__ __launch_bounds__(256, 2) void gemm_nt_big_x3_kernel(
     const float* __restrict__ G, int ldg, int64_t sGo, int64_t sGi, const float* __restrict__ X, int ldx, int64_t sXo,
     int64_t sXi, int M, int Kx, int Nc, int n_inner, int n_batch, int nsplit, float* __restrict__ part, int tilesM, int tilesK,
     int vecG, int vecX) {
@@ -223,41 +281,65 @@ __global__ __launch_bounds__(256, X3_WPS) void gemm_nt_big_x3_kernel(
     int64_t g = (int64_t)split * T / nsplit;
     const int64_t g_end = (int64_t)(split + 1) * T / nsplit;
     const int lrow = tid >> 1, lh = tid & 1;               // loader: thread = (row, 8-column half of the step)
+    const bool okG = m0 + lrow < M, okX = x0 + lrow < Kx;
+    const int64_t offG = (int64_t)min(m0 + lrow, M - 1) * ldg + 8 * lh, offX = (int64_t)min(x0 + lrow, Kx - 1) * ldx + 8 * lh;
     float rg[8], rx[8];
     auto gload = [&](int64_t gs) {
         const int batch = (int)(gs / spb);
-        const int c0 = (int)(gs % spb) * X3_BK + 8 * lh;
+        const int c0 = (int)(gs % spb) * X3_BK;
         const int bo = batch / n_inner, bi = batch % n_inner;
-        ld8_guard(G + bo * sGo + bi * sGi + (int64_t)(m0 + lrow) * ldg, c0, Nc, m0 + lrow < M, vecG, rg);
-        ld8_guard(X + bo * sXo + bi * sXi + (int64_t)(x0 + lrow) * ldx, c0, Nc, x0 + lrow < Kx, vecX, rx);
+        if (FAST) {
+            const float* gp = G + bo * sGo + bi * sGi + offG + c0;
+            const float* xp = X + bo * sXo + bi * sXi + offX + c0;
+            const float4 a0 = *reinterpret_cast<const float4*>(gp), a1 = *reinterpret_cast<const float4*>(gp + 4);
+            const float4 b0 = *reinterpret_cast<const float4*>(xp), b1 = *reinterpret_cast<const float4*>(xp + 4);
+            rg[0] = a0.x; rg[1] = a0.y; rg[2] = a0.z; rg[3] = a0.w; rg[4] = a1.x; rg[5] = a1.y; rg[6] = a1.z; rg[7] = a1.w;
+            rx[0] = b0.x; rx[1] = b0.y; rx[2] = b0.z; rx[3] = b0.w; rx[4] = b1.x; rx[5] = b1.y; rx[6] = b1.z; rx[7] = b1.w;
+        } else {
+            ld8_guard(G + bo * sGo + bi * sGi + (int64_t)(m0 + lrow) * ldg, c0 + 8 * lh, Nc, okG, vecG, rg);
+            ld8_guard(X + bo * sXo + bi * sXi + (int64_t)(x0 + lrow) * ldx, c0 + 8 * lh, Nc, okX, vecX, rx);
+        }
     };
-    auto lstore = [&]() {
-        u32x4 p1, p2, p3;
-        unsigned char* base = x3_lds + lrow * X3_PITCH + lh * 16;
-        split8(rg, p1, p2, p3);
-        *reinterpret_cast<u32x4*>(base) = p1;
-        *reinterpret_cast<u32x4*>(base + X3_PIECE) = p2;
-        *reinterpret_cast<u32x4*>(base + 2 * X3_PIECE) = p3;
-        split8(rx, p1, p2, p3);
-        *reinterpret_cast<u32x4*>(base + X3_OPER) = p1;
-        *reinterpret_cast<u32x4*>(base + X3_OPER + X3_PIECE) = p2;
-        *reinterpret_cast<u32x4*>(base + X3_OPER + 2 * X3_PIECE) = p3;
+    auto zero_rows = [&]() {
+        if (FAST) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                rg[j] = okG ? rg[j] : 0.f;
+                rx[j] = okX ? rx[j] : 0.f;
+            }
+        }
+    };
+    unsigned char* wbase = x3_lds + lrow * X3_PITCH + lh * 16;
+    auto lwrite = [&](const u32x4 (&pa)[3], const u32x4 (&pb)[3]) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            *reinterpret_cast<u32x4*>(wbase + p * X3_PIECE) = pa[p];
+            *reinterpret_cast<u32x4*>(wbase + X3_OPER + p * X3_PIECE) = pb[p];
+        }
     };
     bool live[2][2];
+    bool all_live = true;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) live[i][j] = (m0 + wm * 64 + i * 32 < M) && (x0 + wn * 64 + j * 32 < Kx);
+        for (int j = 0; j < 2; ++j) {
+            live[i][j] = (m0 + wm * 64 + i * 32 < M) && (x0 + wn * 64 + j * 32 < Kx);
+            all_live = all_live && live[i][j];
+        }
     const unsigned char* sa = x3_lds + (wm * 64 + lr) * X3_PITCH + lk * 16;
     const unsigned char* sb = x3_lds + X3_OPER + (wn * 64 + lr) * X3_PITCH + lk * 16;
+    u32x4 pa[3], pb[3];
     if (g < g_end) {
         gload(g);
-        lstore();
+        zero_rows();
+        split8(rg, pa[0], pa[1], pa[2]);
+        split8(rx, pb[0], pb[1], pb[2]);
+        if (g + 1 < g_end) gload(g + 1);
+        lwrite(pa, pb);
     }
     __syncthreads();
     for (; g < g_end; ++g) {
-        const bool have_next = g + 1 < g_end;
-        if (have_next) gload(g + 1);
+        const bool have1 = g + 1 < g_end;
         bf16x8 a[2][3], b[2][3];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -266,22 +348,24 @@ __global__ __launch_bounds__(256, X3_WPS) void gemm_nt_big_x3_kernel(
                 a[i][p] = *reinterpret_cast<const bf16x8*>(sa + p * X3_PIECE + i * 32 * X3_PITCH);
                 b[i][p] = *reinterpret_cast<const bf16x8*>(sb + p * X3_PIECE + i * 32 * X3_PITCH);
             }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                if (live[i][j]) {
-                    f32x16 c = acc[i][j];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);
-                    acc[i][j] = c;
-                }
+        if (all_live) {
+            X3_MMA6(acc[0][0], a[0], b[0]) X3_MMA6(acc[0][1], a[0], b[1])
+            zero_rows();
+            split8(rg, pa[0], pa[1], pa[2]);
+            X3_MMA6(acc[1][0], a[1], b[0]) X3_MMA6(acc[1][1], a[1], b[1])
+            split8(rx, pb[0], pb[1], pb[2]);
+        } else {
+            if (live[0][0]) { X3_MMA6(acc[0][0], a[0], b[0]) }
+            if (live[0][1]) { X3_MMA6(acc[0][1], a[0], b[1]) }
+            if (live[1][0]) { X3_MMA6(acc[1][0], a[1], b[0]) }
+            if (live[1][1]) { X3_MMA6(acc[1][1], a[1], b[1]) }
+            zero_rows();
+            split8(rg, pa[0], pa[1], pa[2]);
+            split8(rx, pb[0], pb[1], pb[2]);
+        }
+        if (g + 2 < g_end) gload(g + 2);
         __syncthreads();                                       // everybody has read its fragments
-        if (have_next) lstore();
+        if (have1) lwrite(pa, pb);
         __syncthreads();
     }
     float* P = part + (int64_t)split * M * Kx;
@@ -304,11 +388,16 @@ __global__ __launch_bounds__(256, X3_WPS) void gemm_nt_big_x3_kernel(
 int hpcs_x3_nt_big_launch(const float* G, int ldg, int64_t sGo, int64_t sGi, const float* X, int ldx, int64_t sXo, int64_t sXi, int M,
                           int Kx, int Nc, int n_inner, int n_batch, int nsplit, float* part, int tilesM, int tilesK, int vecG, int vecX,
                           long blocks, hipStream_t st) {
-    static const bool attr_ok = hipFuncSetAttribute((const void*)gemm_nt_big_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                    X3_STAGE) == hipSuccess;
+    static const bool attr_ok =
+        hipFuncSetAttribute((const void*)gemm_nt_big_x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_STAGE) == hipSuccess &&
+        hipFuncSetAttribute((const void*)gemm_nt_big_x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_STAGE) == hipSuccess;
     if (!attr_ok) return HPCS_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(gemm_nt_big_x3_kernel, dim3((unsigned)blocks), dim3(256), X3_STAGE, st, G, ldg, sGo, sGi, X, ldx, sXo, sXi, M, Kx,
-                       Nc, n_inner, n_batch, nsplit, part, tilesM, tilesK, vecG, vecX);
+    if (vecG && vecX && Nc % X3_BK == 0)
+        hipLaunchKernelGGL(gemm_nt_big_x3_kernel<true>, dim3((unsigned)blocks), dim3(256), X3_STAGE, st, G, ldg, sGo, sGi, X, ldx, sXo, sXi,
+                           M, Kx, Nc, n_inner, n_batch, nsplit, part, tilesM, tilesK, vecG, vecX);
+    else
+        hipLaunchKernelGGL(gemm_nt_big_x3_kernel<false>, dim3((unsigned)blocks), dim3(256), X3_STAGE, st, G, ldg, sGo, sGi, X, ldx, sXo, sXi,
+                           M, Kx, Nc, n_inner, n_batch, nsplit, part, tilesM, tilesK, vecG, vecX);
     return HPCS_OK;
 }
 
@@ -319,12 +408,12 @@ extern "C" int hpcs_gemm_tn_x3(const float* At, int lda, const float* Bm, int ld
     if (M <= 0 || Nc <= 0 || K <= 0 || n_outer < 0 || n_inner <= 0 || lda < M || ldb < Nc || ldc < Nc) return HPCS_ERR_SHAPE;
     if (n_outer == 0) return HPCS_OK;
     static const bool attr_ok = hipFuncSetAttribute((const void*)gemm_tn_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                    X3_NBUF * X3_STAGE) == hipSuccess;
+                                                    X3_STAGE) == hipSuccess;
     if (!attr_ok) return HPCS_ERR_UNSUPPORTED;
     const int tm = hpcs_cdiv(M, X3_BM), tn = hpcs_cdiv(Nc, X3_BN);
     const long total = (long)tm * tn * n_outer * n_inner;
     if (total > 0x7fffffffL) return HPCS_ERR_SHAPE;
-    hipLaunchKernelGGL(gemm_tn_x3_kernel, dim3((unsigned)total), dim3(256), X3_NBUF * X3_STAGE, (hipStream_t)stream, At, lda, Bm, ldb,
+    hipLaunchKernelGGL(gemm_tn_x3_kernel, dim3((unsigned)total), dim3(256), X3_STAGE, (hipStream_t)stream, At, lda, Bm, ldb,
                        strideB_o, strideB_i, C, ldc, strideC_o, strideC_i, M, Nc, K, n_inner, rowbias, accumulate, tm, tn,
                        (unsigned)total);
     HPCS_CHECK_LAUNCH();
