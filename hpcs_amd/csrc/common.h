@@ -20,7 +20,7 @@ static inline int hpcs_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // global state.  hpcs_debug_set_tuning (tests only) replaces a value in place.
 struct HpcsTuning {
     int nt_wg_target;      // HPCS_NT_WG_TARGET   weight-gradient GEMM: workgroups per launch aimed for (0 = built-in)
-    int nt_big_min;        // HPCS_NT_BIG_MIN     smallest output side that takes the 128 x 128 weight-gradient kernel (300)
+    int nt_big_min;        // HPCS_NT_BIG_MIN     smallest output side that takes the 128 x 128 weight-gradient kernel (0 = 128 / 300)
     int nt_big_wg;         // HPCS_NT_BIG_WG      workgroups of that kernel (512 = two per CU)
     int gemm_vecstore;     // HPCS_GEMM_VECSTORE  16-byte epilogue stores through LDS (1)
     int gemm_tn_guarded;   // HPCS_GEMM_TN_GUARDED bounds-tested operand loader (0)

@@ -118,7 +118,7 @@ static int env_int(const char* name, int dflt) {
 static HpcsTuning read_tuning() {
     HpcsTuning t;
     t.nt_wg_target = env_int("HPCS_NT_WG_TARGET", 0);
-    t.nt_big_min = env_int("HPCS_NT_BIG_MIN", 300);
+    t.nt_big_min = env_int("HPCS_NT_BIG_MIN", 0);        // 0: 128 with the bf16x3 kernels, 300 with the fma-chain ones (gemm.hip)
     t.nt_big_wg = env_int("HPCS_NT_BIG_WG", 512);
     t.gemm_vecstore = env_int("HPCS_GEMM_VECSTORE", 1) != 0;
     t.gemm_tn_guarded = env_int("HPCS_GEMM_TN_GUARDED", 0) != 0;

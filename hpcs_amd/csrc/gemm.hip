@@ -1044,7 +1044,8 @@ NtPlan nt_plan(int M, int Kx, int Nc, int n_batch) {
     NtPlan p;
     const long WG = nt_wg_target();
     // 128 x 128 tiles (gemm_nt_big_kernel) from 300 x 300 outputs up: VNStdFeature's vn1 / vn2 weight gradients
-    const int big_min = hpcs_tuning().nt_big_min;
+    // (r04: from 128 x 128 up once the 128-tile kernel runs on the bf16 matrix cores: the heads' 256 x 256 gradients too)
+    const int big_min = hpcs_tuning().nt_big_min > 0 ? hpcs_tuning().nt_big_min : (hpcs_tuning().gemm_x3 ? 128 : 300);
     p.tile = (M >= big_min && Kx >= big_min) ? 128 : 64;
     p.tilesM = hpcs_cdiv(M, p.tile);
     p.tilesK = hpcs_cdiv(Kx, p.tile);

