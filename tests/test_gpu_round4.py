@@ -489,3 +489,39 @@ def test_in_launch_split_reduction_is_reproducible_under_traffic():
         torch.cuda.synchronize()
         assert int(differ) == 0, (M, Kx, Nc, nb, int(differ))
         assert int(tickets.abs().sum()) == 0
+
+
+@pytest.mark.parametrize("M,K,Nc,nb,ni,bias,acc", [(682, 341, 1024, 2, 3, True, False), (341, 682, 1024, 2, 3, False, False),
+                                                   (340, 341, 3072, 2, 1, False, True), (256, 256, 1000, 3, 1, False, False),
+                                                   (65, 7, 130, 2, 1, True, True), (130, 300, 33, 1, 1, False, False)])
+def test_bf16x3_gemm_is_as_close_to_fp64_as_the_fma_chain(M, K, Nc, nb, ni, bias, acc, tuning):
+    """csrc/gemm_x3.hip: the large dense layers evaluate every fp32 product as six exact bf16-piece products on the bf16
+    matrix cores with fp32 accumulation.  Against the fp64 product of the same fp32 operands its error must not exceed the
+    fma-chain kernel's (hpcs_gemm_tn with HPCS_GEMM_X3=0: the k-ordered chain that equals the reference's sgemm) by more than
+    a small factor, on the step's shapes and on ragged ones (edge tiles, K not a multiple of 16, odd column counts, row bias,
+    accumulation, the [B,K,3,L] walk as 3B matrices); also with operands spanning 12 orders of magnitude per row."""
+    from hpcs_amd import _lib
+    call = _lib.call
+    W = det_normalish((M, K), 9601 + M) / K ** 0.5
+    X = det_normalish((nb, K, ni, Nc), 9602 + K)
+    X[:, : max(1, K // 3)] *= 1e-6                      # wide dynamic range inside every dot product
+    X[:, -max(1, K // 5):] *= 1e+3
+    rb = det_normalish((nb * ni, M), 9603) if bias else None
+    C0 = det_normalish((nb, M, ni, Nc), 9604)
+    want = torch.einsum("mk,bkin->bmin", W.double(), X.double())
+    if bias:
+        want = want + rb.double().view(nb, ni, M).permute(0, 2, 1).unsqueeze(-1)
+    if acc:
+        want = want + C0.double()
+    At = W.t().contiguous().to(dev)
+    Xd = X.to(dev)
+    errs = {}
+    for x3 in (0, 1):
+        tuning("HPCS_GEMM_X3", x3)
+        out = C0.to(dev).clone()
+        call("hpcs_gemm_tn", At, M, Xd, ni * Nc, K * ni * Nc, Nc, out, ni * Nc, M * ni * Nc, Nc, M, Nc, K, nb, ni,
+             None if rb is None else rb.to(dev), 1 if acc else 0)
+        d = out.cpu().double() - want
+        errs[x3] = (float(d.norm() / want.norm()), float(d.abs().max() / want.abs().max()))
+    assert errs[1][0] <= 1.25 * errs[0][0] + 1e-9 and errs[1][1] <= 2.0 * errs[0][1] + 1e-9, errs
+    assert errs[1][0] <= 1e-6, errs
