@@ -6,6 +6,24 @@
 
 constexpr float VN_EPS = 1e-6f;
 
+// a / b for b > 0 well inside the normal range (norms + eps, |d|^2 + eps) in the BACKWARD point functions: v_rcp_f32 and one
+// Newton correction -- 4 instructions against the ~10 of the IEEE sequence (v_div_scale x2, v_rcp, 4-5 fma, v_div_fmas,
+// v_div_fixup), and the same correctly rounded quotient on every one of 4.2 M random operand pairs (scripts/micro/div_ulp.hip).
+// The backward executes eight of them per (channel, position).  The forward point functions keep '/': the quotient is
+// identical, but the open-coded sequence changes how the compiler packs and contracts the surrounding sums, and the forward
+// error ensemble (tests/test_gpu_round2.py) is pinned to the rounding pattern it was measured on.  -DHPCS_VN_IEEE_DIV
+// restores '/' everywhere.
+__device__ __forceinline__ float vn_div(float a, float b) {
+#ifdef HPCS_VN_IEEE_DIV
+    return a / b;
+#else
+    const float r = __builtin_amdgcn_rcpf(b);
+    const float q = a * r;
+    const float e = __builtin_fmaf(-b, q, a);
+    return __builtin_fmaf(e, r, q);
+#endif
+}
+
 // ------------------------------------------------------------------------------------------------ a3
 struct VnPoint {   // recomputed forward state of one (b,c,l) vector
     float p[3], d[3], n, xhat, nb, q[3], dot, dsq;
@@ -58,12 +76,12 @@ __device__ __forceinline__ void vn_lrelu_bwd_point(const VnPoint& s, const float
     }
     const float a1 = 1.f - slope;
     const float den = s.dsq + VN_EPS;
-    const float t = s.dot / den;
+    const float t = vn_div(s.dot, den);
     const float gdot = g[0] * s.d[0] + g[1] * s.d[1] + g[2] * s.d[2];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        gq[a] = g[a] - a1 * (gdot / den) * s.d[a];
-        gd[a] = -a1 * (t * g[a] + gdot * (s.q[a] - 2.f * t * s.d[a]) / den);
+        gq[a] = g[a] - a1 * vn_div(gdot, den) * s.d[a];
+        gd[a] = -a1 * (t * g[a] + vn_div(gdot * (s.q[a] - 2.f * t * s.d[a]), den));
     }
 }
 
@@ -77,14 +95,14 @@ __device__ __forceinline__ void vn_bn_bwd_point(const VnPoint& s, const float (&
         return;
     }
     const float gqp = gq[0] * s.p[0] + gq[1] * s.p[1] + gq[2] * s.p[2];
-    const float gnb = gqp / s.n;
-    float gn = -gqp * s.nb / (s.n * s.n);
+    const float gnb = vn_div(gqp, s.n);
+    float gn = vn_div(-gqp * s.nb, s.n * s.n);
     const float gxh = gnb * ga;
     if (training) gn += rs * (gxh - m1 - s.xhat * m2);
     else gn += rs * gxh;
     const float pn = s.n - VN_EPS;
-    const float sc = s.nb / s.n;
-    const float dirw = pn > 0.f ? gn / pn : 0.f;
+    const float sc = vn_div(s.nb, s.n);
+    const float dirw = pn > 0.f ? vn_div(gn, pn) : 0.f;
 #pragma unroll
     for (int a = 0; a < 3; ++a) gp[a] = gq[a] * sc + dirw * s.p[a];
 }
