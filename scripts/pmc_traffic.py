@@ -19,7 +19,7 @@ import sys
 # Kernels whose GLOBAL loads are contiguous 16 B/lane streaming reads (float4 / 128-bit staging loads; list made by scanning
 # csrc/*.hip for 16-byte global loads, r03): FETCH_SIZE counts half of their bytes.  r02 doubled the GEMMs only, which left the
 # vectorised element-wise passes under-counted (vn_bwd_apply reported 183 MB fetched where it reads a 330 MB PD + 165 MB g).
-WIDE = ("gemm_tn_kernel", "gemm_nt_kernel", "gemm_nt_big_kernel", "gemm_nt_edge_kernel", "_vec_kernel", "vn_bwd_apply_kernel",
+WIDE = ("gemm_tn_kernel", "gemm_nt_kernel", "gemm_nt_big_kernel", "gemm_nt_big_x3_kernel", "gemm_nt_edge_kernel", "_vec_kernel", "vn_bwd_apply_kernel",
         "vn_apply_pool_fwd_kernel", "vn_apply_pool_tile_kernel", "k2all_kernel", "edge_gather_bwd_center",
         "edge_segsum_kernel", "edge_gather_bwd_inv_kernel", "edge_grad_reduce_inv_kernel", "edge_grad_reduce_slab_kernel",
         "rowsum_wave_kernel", "rowsum_long_kernel", "vn_rc_stats_kernel", "vn_rc_apply_fwd_kernel", "vn_rc_bwd_reduce_kernel", "vn_rc_bwd_apply_kernel", "hpcs_zero_kernel")
