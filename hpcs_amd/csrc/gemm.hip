@@ -10,6 +10,10 @@
 // conflict-free ds_read_b32 per lane (lanes 0-31 = 32 consecutive floats of row k, lanes 32-63 = row k+1).
 // Global->LDS goes through registers, double-buffered, one barrier per K step.
 // Block ids are remapped so that the row tiles sharing one activation panel run on the same XCD (L2 reuse).
+//
+// The large shapes (gemm_tn with M > 64, weight gradients with both output sides >= 128) are routed to csrc/gemm_x3.hip by
+// default: fp32 operands and results, every product formed from three exact bf16 pieces per operand on the bf16 matrix
+// cores (hpcs_tuning().gemm_x3; HPCS_GEMM_X3=0 keeps them here).
 #include <type_traits>
 
 #include "common.h"
