@@ -122,7 +122,7 @@ static HpcsTuning read_tuning() {
     t.nt_big_wg = env_int("HPCS_NT_BIG_WG", 512);
     t.gemm_vecstore = env_int("HPCS_GEMM_VECSTORE", 1) != 0;
     t.gemm_tn_guarded = env_int("HPCS_GEMM_TN_GUARDED", 0) != 0;
-    t.gemm_x3 = env_int("HPCS_GEMM_X3", 1) != 0;
+    t.gemm_x3 = env_int("HPCS_GEMM_X3", 1);
     const char* k = getenv("HPCS_KNN_KERNEL");
     t.knn_kernel = !k || !*k ? 0 : (k[0] == 't' ? 1 : (k[0] == 'b' ? (k[1] == 'q' && k[2] == '2' ? 5 : 4) : 2));
     t.sampled_v = env_int("HPCS_SAMPLED_V", 4) == 8 ? 8 : 4;

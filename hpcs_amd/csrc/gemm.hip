@@ -1209,7 +1209,8 @@ extern "C" int hpcs_gemm_tn(const float* At, int lda, const float* Bm, int ldb, 
     // The large dense layers (M > 64) take the bf16x3 kernel (csrc/gemm_x3.hip): fp32-accurate products on the bf16 matrix
     // cores, 1.4-1.6x the fma-chain kernel below; HPCS_GEMM_X3=0 keeps the fma chain (A/B, and the form whose k-ordered
     // rounding sequence the kNN and the graph-operand GEMM are pinned to -- those never come here).
-    if (M > 64 && hpcs_tuning().gemm_x3)
+    // (its loads address one operand matrix with 32-bit byte offsets)
+    if (M > 64 && hpcs_tuning().gemm_x3 && (int64_t)(K + 16) * lda * 4 < ((int64_t)1 << 31) && (int64_t)(K + 16) * ldb * 4 < ((int64_t)1 << 31))
         return hpcs_gemm_tn_x3(At, lda, Bm, ldb, strideB_o, strideB_i, C, ldc, strideC_o, strideC_i, M, Nc, K, n_outer, n_inner,
                                rowbias, accumulate, stream);
     const int BMsel = M > 64 ? 128 : 64;

@@ -14,9 +14,15 @@
 //
 // Tile 128 x 128 x 16, four waves of 64 x 64 (2 x 2 v_mfma_f32_32x32x16_bf16 tiles).  Both operands are K-major in memory
 // ([k][m], [k][n]); the MFMA wants 8 consecutive k per lane.  The loader thread owns one (row, 8 k) strip -- eight coalesced
-// 4-byte loads, one per k -- splits it in registers and writes one 16-byte [row][k8] piece per split level to LDS (row pitch
-// 48 bytes: conflict-free for the 16-byte fragment reads), so the transposition costs nothing and no split copy of any tensor
-// ever exists in HBM.  Register-staged prefetch of the next k-step, LDS double-buffered, one barrier per step.
+// 4-byte buffer loads, one per k, the row offset in a scalar register -- splits it in registers and writes one 16-byte
+// [row][k8] piece per split level to LDS (row pitch 48 bytes: conflict-free for the 16-byte fragment reads), so the
+// transposition costs nothing and no split copy of any tensor ever exists in HBM.  Register-staged prefetch two K steps ahead.
+//
+// The loop is priced in vector-issue slots, not in MFMA cycles: an MFMA holds the SIMD's issue port for 8 of its 32 cycles and
+// every VALU instruction for 4, and on random data the chip lowers its clock as the loop gets denser (MI355X_MICROARCH.md
+// "DVFS give-back").  The first form of this loader spent 185 VALU instructions per wave and K step (64-bit address
+// arithmetic per load, min-clamps, tail selects) beside 24 MFMAs; buffer loads with scalar row offsets and the descriptor's
+// range check (rows k >= K read as zeros) leave the 88 of the split itself: 141-157 -> 159-175 TFLOP/s on the VN shapes.
 #include "common.h"
 
 namespace {
@@ -65,31 +71,35 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4& p1, u32x4& p2
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);        \
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
 
+// Raw buffer descriptor over one operand matrix: loads take a 32-bit per-lane byte offset plus a scalar one, and anything at
+// or beyond `bytes` reads as zero -- the K tail needs no clamp and no select, and no 64-bit address arithmetic is left.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t x3_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long p = (unsigned long long)base;
+    const unsigned long long q = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)p) |
+                                 ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(p >> 32)) << 32);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)q, 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+}
+
 // Software pipeline of one workgroup (single LDS stage, two register sets for the raw operands):
 //   step kt:  request the raw operands of step kt+2 | read the fragments of step kt from LDS | the 24 MFMAs of step kt
 //             INTERLEAVED with the VALU split of step kt+1's raw operands (the matrix pipe runs under the ~100 split
 //             instructions instead of after them: sched_group_barrier) | barrier | write the split pieces | barrier.
 template <bool FULL>
-__device__ __forceinline__ void x3_tn_tile(const float* __restrict__ Ag, int lda, const float* __restrict__ Bg, int ldb, int K,
-                                           int lh, unsigned char* wbase, const unsigned char* sa, const unsigned char* sb,
+__device__ __forceinline__ void x3_tn_tile(__amdgpu_buffer_rsrc_t rsA, unsigned voA, int lda, __amdgpu_buffer_rsrc_t rsB, unsigned voB,
+                                           int ldb, int K, int lh,
+                                           unsigned char* wbase, const unsigned char* sa, const unsigned char* sb,
                                            const bool (&live)[2][2], f32x16 (&acc)[2][2]) {
+    // lh (the k half this wave's loader threads own) is wave-uniform: the row offsets below are scalar
     float ra[8], rb[8];
     auto gload = [&](int k0) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int k = min(k0 + 8 * lh + j, K - 1);                     // clamped; zeroed before the split
-            ra[j] = Ag[(int64_t)k * lda];
-            rb[j] = Bg[(int64_t)k * ldb];
+            const int k = k0 + 8 * lh + j;                                 // rows k >= K are beyond the descriptors: zeros
+            ra[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsA, voA, k * lda * 4, 0));
+            rb[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsB, voB, k * ldb * 4, 0));
         }
     };
-    auto zero_tail = [&](int k0) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const bool in = k0 + 8 * lh + j < K;
-            ra[j] = in ? ra[j] : 0.f;
-            rb[j] = in ? rb[j] : 0.f;
-        }
-    };
+    auto zero_tail = [&](int) {};
     auto lwrite = [&](const u32x4 (&pa)[3], const u32x4 (&pb)[3]) {
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
@@ -140,55 +150,14 @@ __device__ __forceinline__ void x3_tn_tile(const float* __restrict__ Ag, int lda
     }
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(
-    const float* __restrict__ At, int lda, const float* __restrict__ Bm, int ldb, int64_t sBo, int64_t sBi,
-    float* __restrict__ C, int ldc, int64_t sCo, int64_t sCi, int M, int Nc, int K, int n_inner,
-    const float* __restrict__ rowbias, int accumulate, int tilesM, int tilesN, unsigned total) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char x3_lds[];
-    const unsigned logical = hpcs_xcd_remap(blockIdx.x, total);
-    const int rowTile = logical % tilesM;
-    const unsigned t1 = logical / tilesM;
-    const int colTile = t1 % tilesN;
-    const int batch = t1 / tilesN;
-    const int bo = batch / n_inner, bi = batch % n_inner;
-    const float* Bp = Bm + bo * sBo + bi * sBi;
-    float* Cp = C + bo * sCo + bi * sCi;
-    const float* bias = rowbias ? rowbias + (int64_t)batch * M : nullptr;
-    const int m0 = rowTile * X3_BM, n0 = colTile * X3_BN;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// Epilogue of the tn kernels.  D layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).  Through a wave-private LDS
+// patch (the operand stages are dead after the loop's last barrier) every lane owns 4 CONSECUTIVE columns and the tile leaves
+// as 16-byte stores, eight 128-byte row segments per instruction (vn1's forward writes 268 MB), as in csrc/gemm.hip.
+__device__ __forceinline__ void x3_tn_store(unsigned char* x3_lds, const f32x16 (&acc)[2][2], float* __restrict__ C, float* __restrict__ Cp,
+                                            int ldc, int64_t sCo, int64_t sCi, int M, int Nc, int m0, int n0, int wave, int lane,
+                                            const float* __restrict__ bias, int accumulate) {
     const int wm = wave >> 1, wn = wave & 1;
-    // ---- loader: thread = (row, k half); rows beyond the matrix are clamped (their outputs are never stored)
-    const int lrow = tid & 127, lh = tid >> 7;
-    const float* Ag = At + min(m0 + lrow, M - 1);
-    const float* Bg = Bp + min(n0 + lrow, Nc - 1);
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    bool live[2][2];
-    bool all_live = true;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            live[i][j] = (m0 + wm * 64 + i * 32 < M) && (n0 + wn * 64 + j * 32 < Nc);
-            all_live = all_live && live[i][j];
-        }
     const int lr = lane & 31, lk = lane >> 5;
-    unsigned char* wbase = x3_lds + lrow * X3_PITCH + lh * 16;
-    const unsigned char* sa = x3_lds + (wm * 64 + lr) * X3_PITCH + lk * 16;
-    const unsigned char* sb = x3_lds + X3_OPER + (wn * 64 + lr) * X3_PITCH + lk * 16;
-    // (the branch is per wave; both bodies hold the same barriers)
-    if (all_live) x3_tn_tile<true>(Ag, lda, Bg, ldb, K, lh, wbase, sa, sb, live, acc);
-    else x3_tn_tile<false>(Ag, lda, Bg, ldb, K, lh, wbase, sa, sb, live, acc);
-    // ---- epilogue: D layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).  Through a wave-private LDS patch
-    // (the operand stage is dead after the loop's last barrier) every lane owns 4 CONSECUTIVE columns and the tile leaves as
-    // 16-byte stores, eight 128-byte row segments per instruction (vn1's forward writes 268 MB), as in csrc/gemm.hip.
     const bool vecC = (ldc % 4 == 0) && (sCo % 4 == 0) && (sCi % 4 == 0) && ((((uintptr_t)C) & 15u) == 0) && (Nc % 4 == 0);
     constexpr int PP = 36;
     float* patch = reinterpret_cast<float*>(x3_lds) + wave * (32 * PP);
@@ -233,6 +202,58 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(
                 }
             }
         }
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(
+    const float* __restrict__ At, int lda, const float* __restrict__ Bm, int ldb, int64_t sBo, int64_t sBi,
+    float* __restrict__ C, int ldc, int64_t sCo, int64_t sCi, int M, int Nc, int K, int n_inner,
+    const float* __restrict__ rowbias, int accumulate, int tilesM, int tilesN, unsigned total) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char x3_lds[];
+    const unsigned logical = hpcs_xcd_remap(blockIdx.x, total);
+    const int rowTile = logical % tilesM;
+    const unsigned t1 = logical / tilesM;
+    const int colTile = t1 % tilesN;
+    const int batch = t1 / tilesN;
+    const int bo = batch / n_inner, bi = batch % n_inner;
+    const float* Bp = Bm + bo * sBo + bi * sBi;
+    float* Cp = C + bo * sCo + bi * sCi;
+    const float* bias = rowbias ? rowbias + (int64_t)batch * M : nullptr;
+    const int m0 = rowTile * X3_BM, n0 = colTile * X3_BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    // ---- loader: thread = (row, k half).  Columns beyond the matrix read finite neighbours (their outputs are never stored)
+    // or, past the end of the operand, zeros.
+    const int lrow = tid & 127;
+    const int lh = __builtin_amdgcn_readfirstlane(tid >> 7);
+    const __amdgpu_buffer_rsrc_t rsA = x3_rsrc(At, (unsigned)K * (unsigned)lda * 4u);
+    const __amdgpu_buffer_rsrc_t rsB = x3_rsrc(Bp, ((unsigned)(K - 1) * (unsigned)ldb + (unsigned)Nc) * 4u);
+    const unsigned voA = (unsigned)(m0 + lrow) * 4u, voB = (unsigned)(n0 + lrow) * 4u;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    bool live[2][2];
+    bool all_live = true;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            live[i][j] = (m0 + wm * 64 + i * 32 < M) && (n0 + wn * 64 + j * 32 < Nc);
+            all_live = all_live && live[i][j];
+        }
+    const int lr = lane & 31, lk = lane >> 5;
+    unsigned char* wbase = x3_lds + lrow * X3_PITCH + (tid >> 7) * 16;
+    const unsigned char* sa = x3_lds + (wm * 64 + lr) * X3_PITCH + lk * 16;
+    const unsigned char* sb = x3_lds + X3_OPER + (wn * 64 + lr) * X3_PITCH + lk * 16;
+    // (the branch is per wave; both bodies hold the same barriers)
+    if (all_live) x3_tn_tile<true>(rsA, voA, lda, rsB, voB, ldb, K, lh, wbase, sa, sb, live, acc);
+    else x3_tn_tile<false>(rsA, voA, lda, rsB, voB, ldb, K, lh, wbase, sa, sb, live, acc);
+    x3_tn_store(x3_lds, acc, C, Cp, ldc, sCo, sCi, M, Nc, m0, n0, wave, lane, bias, accumulate);
 }
 
 // ---- weight gradients of the large layers: dW (M x Kx) = sum_b G[b] (M x Nc) X[b]^T (Kx x Nc), split over the column steps.
@@ -284,31 +305,33 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_big_x3_kernel(
     const bool okG = m0 + lrow < M, okX = x0 + lrow < Kx;
     const int64_t offG = (int64_t)min(m0 + lrow, M - 1) * ldg + 8 * lh, offX = (int64_t)min(x0 + lrow, Kx - 1) * ldx + 8 * lh;
     float rg[8], rx[8];
-    auto gload = [&](int64_t gs) {
-        const int batch = (int)(gs / spb);
-        const int c0 = (int)(gs % spb) * X3_BK;
-        const int bo = batch / n_inner, bi = batch % n_inner;
+    // The loader walks the step list in order: (batch, column) advance incrementally, the batch's base pointers are
+    // recomputed only when the batch changes (the division per step cost ~200 scalar instructions).
+    int ld_batch = (int)(g / spb), ld_c0 = (int)(g % spb) * X3_BK;
+    const float* ld_gp = G + (ld_batch / n_inner) * sGo + (ld_batch % n_inner) * sGi;
+    const float* ld_xp = X + (ld_batch / n_inner) * sXo + (ld_batch % n_inner) * sXi;
+    auto gload = [&]() {
         if (FAST) {
-            const float* gp = G + bo * sGo + bi * sGi + offG + c0;
-            const float* xp = X + bo * sXo + bi * sXi + offX + c0;
+            // rows beyond the matrix are clamped to the last row: their products land in rows / columns that are never stored
+            const float* gp = ld_gp + offG + ld_c0;
+            const float* xp = ld_xp + offX + ld_c0;
             const float4 a0 = *reinterpret_cast<const float4*>(gp), a1 = *reinterpret_cast<const float4*>(gp + 4);
             const float4 b0 = *reinterpret_cast<const float4*>(xp), b1 = *reinterpret_cast<const float4*>(xp + 4);
             rg[0] = a0.x; rg[1] = a0.y; rg[2] = a0.z; rg[3] = a0.w; rg[4] = a1.x; rg[5] = a1.y; rg[6] = a1.z; rg[7] = a1.w;
             rx[0] = b0.x; rx[1] = b0.y; rx[2] = b0.z; rx[3] = b0.w; rx[4] = b1.x; rx[5] = b1.y; rx[6] = b1.z; rx[7] = b1.w;
         } else {
-            ld8_guard(G + bo * sGo + bi * sGi + (int64_t)(m0 + lrow) * ldg, c0 + 8 * lh, Nc, okG, vecG, rg);
-            ld8_guard(X + bo * sXo + bi * sXi + (int64_t)(x0 + lrow) * ldx, c0 + 8 * lh, Nc, okX, vecX, rx);
+            ld8_guard(ld_gp + (int64_t)(m0 + lrow) * ldg, ld_c0 + 8 * lh, Nc, okG, vecG, rg);
+            ld8_guard(ld_xp + (int64_t)(x0 + lrow) * ldx, ld_c0 + 8 * lh, Nc, okX, vecX, rx);
+        }
+        ld_c0 += X3_BK;
+        if (ld_c0 >= Nc) {
+            ld_c0 = 0;
+            ++ld_batch;
+            ld_gp = G + (ld_batch / n_inner) * sGo + (ld_batch % n_inner) * sGi;
+            ld_xp = X + (ld_batch / n_inner) * sXo + (ld_batch % n_inner) * sXi;
         }
     };
-    auto zero_rows = [&]() {
-        if (FAST) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                rg[j] = okG ? rg[j] : 0.f;
-                rx[j] = okX ? rx[j] : 0.f;
-            }
-        }
-    };
+    auto zero_rows = [&]() {};
     unsigned char* wbase = x3_lds + lrow * X3_PITCH + lh * 16;
     auto lwrite = [&](const u32x4 (&pa)[3], const u32x4 (&pb)[3]) {
 #pragma unroll
@@ -330,11 +353,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_big_x3_kernel(
     const unsigned char* sb = x3_lds + X3_OPER + (wn * 64 + lr) * X3_PITCH + lk * 16;
     u32x4 pa[3], pb[3];
     if (g < g_end) {
-        gload(g);
+        gload();
         zero_rows();
         split8(rg, pa[0], pa[1], pa[2]);
         split8(rx, pb[0], pb[1], pb[2]);
-        if (g + 1 < g_end) gload(g + 1);
+        if (g + 1 < g_end) gload();
         lwrite(pa, pb);
     }
     __syncthreads();
@@ -363,7 +386,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_big_x3_kernel(
             split8(rg, pa[0], pa[1], pa[2]);
             split8(rx, pb[0], pb[1], pb[2]);
         }
-        if (g + 2 < g_end) gload(g + 2);
+        if (g + 2 < g_end) gload();
         __syncthreads();                                       // everybody has read its fragments
         if (have1) lwrite(pa, pb);
         __syncthreads();
@@ -410,6 +433,9 @@ extern "C" int hpcs_gemm_tn_x3(const float* At, int lda, const float* Bm, int ld
     static const bool attr_ok = hipFuncSetAttribute((const void*)gemm_tn_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                     X3_STAGE) == hipSuccess;
     if (!attr_ok) return HPCS_ERR_UNSUPPORTED;
+    // the loader addresses one operand matrix with 32-bit byte offsets (csrc/gemm.hip routes larger operands to the fma chain)
+    if ((int64_t)(K + X3_BK) * lda * 4 >= ((int64_t)1 << 31) || (int64_t)(K + X3_BK) * ldb * 4 >= ((int64_t)1 << 31))
+        return HPCS_ERR_UNSUPPORTED;
     const int tm = hpcs_cdiv(M, X3_BM), tn = hpcs_cdiv(Nc, X3_BN);
     const long total = (long)tm * tn * n_outer * n_inner;
     if (total > 0x7fffffffL) return HPCS_ERR_SHAPE;

@@ -339,6 +339,64 @@ __global__ void vn_apply_fwd_kernel(PdRef pd, const float* __restrict__ mean,
     op[2 * L] = o[2];
 }
 
+// Vector form of vn_apply_fwd_kernel (materialised PD or conv1's two-channel edge feature, L % 4 == 0): four positions per
+// thread, 16-byte loads and stores, (b, c) from the grid -- the scalar form divides a 64-bit element index by L per thread.
+template <bool K2>
+__global__ __launch_bounds__(TPB) void vn_apply_fwd_vec_kernel(const float* __restrict__ PD, const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, int Cout, int Cd, int L, float slope,
+                                                               int flags, float* __restrict__ out, const float* __restrict__ w2,
+                                                               int ldw) {
+    const int c = blockIdx.y, b = blockIdx.z;
+    const int Ctot = Cout + Cd;
+    const int cd = Cd == 1 ? Cout : Cout + c;
+    const int l = ((int)blockIdx.x * TPB + (int)threadIdx.x) * 4;
+    if (l >= L) return;
+    const bool bn = flags & HPCS_VN_BN, act = flags & HPCS_VN_LRELU;
+    const float mu = bn ? mean[c] : 0.f, rs = bn ? rstd[c] : 1.f, ga = bn ? gamma[c] : 1.f, be = bn ? beta[c] : 0.f;
+    const int64_t plane = L;
+    float pv[3][4], dv[3][4];
+    if (K2) {
+        const float wp0 = w2[(int64_t)c * ldw], wp1 = w2[(int64_t)c * ldw + 1];
+        const float wd0 = w2[(int64_t)cd * ldw], wd1 = w2[(int64_t)cd * ldw + 1];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            k2_vec(PD, b, a, plane, l, wp0, wp1, pv[a]);
+            if (act) k2_vec(PD, b, a, plane, l, wd0, wd1, dv[a]);
+        }
+    } else {
+        const float* pp = PD + (((int64_t)b * Ctot + c) * 3) * plane + l;
+        const float* dp = PD + (((int64_t)b * Ctot + cd) * 3) * plane + l;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float4 u = *reinterpret_cast<const float4*>(pp + a * plane);
+            pv[a][0] = u.x; pv[a][1] = u.y; pv[a][2] = u.z; pv[a][3] = u.w;
+            if (act) {
+                const float4 v = *reinterpret_cast<const float4*>(dp + a * plane);
+                dv[a][0] = v.x; dv[a][1] = v.y; dv[a][2] = v.z; dv[a][3] = v.w;
+            }
+        }
+    }
+    float ov[3][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        VnPoint s;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            s.p[a] = pv[a][q];
+            s.d[a] = act ? dv[a][q] : 0.f;
+        }
+        vn_forward_point(s, mu, rs, ga, be, flags);
+        float o[3];
+        vn_output_point(s, slope, flags, o);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) ov[a][q] = o[a];
+    }
+    float* op = out + (((int64_t)b * Cout + c) * 3) * plane + l;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) *reinterpret_cast<float4*>(op + a * plane) = make_float4(ov[a][0], ov[a][1], ov[a][2], ov[a][3]);
+}
+
 // fused mean_pool over groups of pool_k consecutive l: one thread per (b, n).  Each thread owns pool_k contiguous
 // floats per plane, so a wave covers one contiguous span; float4 loads when pool_k % 4 == 0.
 template <bool VEC>
@@ -2202,6 +2260,15 @@ static int vn_apply_fwd_impl(PdRef pd, const float* mean, const float* rstd, con
         else
             hipLaunchKernelGGL((vn_apply_pool_fwd_kernel<false>), grid, dim3(64), 0, st, pd, mean, rstd, gamma, beta, B, Cout,
                                Cd, L, pool_k, slope, flags, out);
+    } else if (pd.idx == nullptr && L % 4 == 0 && L < (int64_t)1 << 31 && B <= 65535 && Cout <= 65535 &&
+               ((((uintptr_t)pd.base | (uintptr_t)out) & 15u) == 0)) {
+        const dim3 grid(hpcs_cdiv(L, (int64_t)TPB * 4), Cout, B);
+        if (pd.w2 != nullptr)
+            hipLaunchKernelGGL((vn_apply_fwd_vec_kernel<true>), grid, dim3(TPB), 0, st, pd.base, mean, rstd, gamma, beta, Cout, Cd,
+                               (int)L, slope, flags, out, pd.w2, pd.ldw);
+        else
+            hipLaunchKernelGGL((vn_apply_fwd_vec_kernel<false>), grid, dim3(TPB), 0, st, pd.base, mean, rstd, gamma, beta, Cout,
+                               Cd, (int)L, slope, flags, out, (const float*)nullptr, 0);
     } else {
         hipLaunchKernelGGL(vn_apply_fwd_kernel, dim3(hpcs_cdiv((int64_t)B * L, TPB), Cout), dim3(TPB), 0, st, pd, mean,
                            rstd, gamma, beta, B, Cout, Cd, L, slope, flags, out);
