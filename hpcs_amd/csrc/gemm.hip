@@ -851,23 +851,43 @@ __global__ __launch_bounds__(256) void gemm_nt_edge_kernel(
 // gridDim.y > 1 writes one partial per slice to `stage` ([slices][M*Kx]) instead of dW (first level of the two-level
 // reduction used when few outputs face many splits: 42x42 EdgeConv gradients over ~1900 splits kept 28 workgroups busy
 // for 55-100 us; two levels spread the same reads over ~900 workgroups).
-__global__ __launch_bounds__(1024) void split_reduce_kernel(const float* __restrict__ part, int nsplit, int slice_len, int M,
-                                                            int Kx, float* __restrict__ dW, int lddw, int accumulate,
-                                                            float* __restrict__ stage) {
-    __shared__ float sh[16][64];
+__global__ __launch_bounds__(256) void split_reduce_kernel(const float* __restrict__ part, int nsplit, int slice_len, int M,
+                                                           int Kx, float* __restrict__ dW, int lddw, int accumulate,
+                                                           float* __restrict__ stage) {
+    // A workgroup owns 256 consecutive outputs; wave w sums the splits s0 + w, s0 + w + 4, ... of its slice, four outputs per
+    // lane (each load is one coalesced 256-byte row piece; eight in flight per lane), then the four wave sums are added in wave
+    // order.  (The first form gave every 64 outputs a 1024-thread workgroup with at most two loads per thread: 58 k waves and
+    // 105 us for vn1's 26 MB of partials.)  Fixed order: bit-reproducible.
+    __shared__ float sh[4][256];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t e = (int64_t)blockIdx.x * 64 + lane;
+    const int64_t e0 = (int64_t)blockIdx.x * 256 + lane;
     const int64_t ne = (int64_t)M * Kx;
     const int s0 = blockIdx.y * slice_len, s1 = min(nsplit, s0 + slice_len);
-    float s = 0.f;
-    if (e < ne)
-        for (int i = s0 + w; i < s1; i += 16) s += part[(int64_t)i * ne + e];
-    sh[w][lane] = s;
-    __syncthreads();
-    if (w == 0 && e < ne) {
-        float t = 0.f;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    bool in[4];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) t += sh[i][lane];
+    for (int j = 0; j < 4; ++j) in[j] = e0 + 64 * j < ne;
+    int i = s0 + w;
+    for (; i + 4 < s1; i += 8) {
+        float a[4], b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a[j] = in[j] ? part[(int64_t)i * ne + e0 + 64 * j] : 0.f;
+            b[j] = in[j] ? part[(int64_t)(i + 4) * ne + e0 + 64 * j] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = (acc[j] + a[j]) + b[j];
+    }
+    if (i < s1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += in[j] ? part[(int64_t)i * ne + e0 + 64 * j] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sh[w][lane + 64 * j] = acc[j];
+    __syncthreads();
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e < ne) {
+        const float t = ((sh[0][threadIdx.x] + sh[1][threadIdx.x]) + sh[2][threadIdx.x]) + sh[3][threadIdx.x];
         if (stage) {
             stage[(int64_t)blockIdx.y * ne + e] = t;
         } else {
@@ -1340,13 +1360,13 @@ static int gemm_nt_impl(const float* G, int ldg, int64_t strideG_o, int64_t stri
     HPCS_CHECK_LAUNCH();
     if (fuse.tickets) return HPCS_OK;
     if (two_level) {
-        hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)hpcs_cdiv(ne, 64), (unsigned)slices), dim3(1024), 0, st,
+        hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)hpcs_cdiv(ne, 256), (unsigned)slices), dim3(256), 0, st,
                            (const float*)ws, p.nsplit, slice_len, M, Kx, dW, lddw, 0, stage);
         HPCS_CHECK_LAUNCH();
-        hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)hpcs_cdiv(ne, 64)), dim3(1024), 0, st, (const float*)stage,
+        hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)hpcs_cdiv(ne, 256)), dim3(256), 0, st, (const float*)stage,
                            slices, slices, M, Kx, dW, lddw, accumulate, (float*)nullptr);
     } else {
-        hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)hpcs_cdiv(ne, 64)), dim3(1024), 0, st, (const float*)ws,
+        hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)hpcs_cdiv(ne, 256)), dim3(256), 0, st, (const float*)ws,
                            p.nsplit, p.nsplit, M, Kx, dW, lddw, accumulate, (float*)nullptr);
     }
     HPCS_CHECK_LAUNCH();
