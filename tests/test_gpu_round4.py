@@ -525,3 +525,44 @@ def test_bf16x3_gemm_is_as_close_to_fp64_as_the_fma_chain(M, K, Nc, nb, ni, bias
         errs[x3] = (float(d.norm() / want.norm()), float(d.abs().max() / want.abs().max()))
     assert errs[1][0] <= 1.25 * errs[0][0] + 1e-9 and errs[1][1] <= 2.0 * errs[0][1] + 1e-9, errs
     assert errs[1][0] <= 1e-6, errs
+
+
+# ---------------------------------------------------------------------------- vector / scalar forms of the per-channel VN layer
+@pytest.mark.parametrize("B,Cin,Cout,N,k,pool", [
+    (2, 42, 21, 128, 20, False),      # EdgeConv shape, L = N k % 4 == 0: vector forward apply, vector backward apply
+    (2, 42, 21, 128, 20, True),       # ... with the fused mean over k (pool_k % 4 == 0: the four positions share one pooled cell)
+    (2, 2, 21, 128, 20, False),       # conv1: two input channels, the pre-activations formed on the fly (K2 instantiations)
+    (2, 2, 21, 128, 20, True),
+    (3, 6, 5, 37, 10, False),         # L = 370: not a multiple of 4 -> the scalar kernels
+    (3, 6, 5, 37, 10, True),          # pool_k = 10: not a multiple of 4 -> scalar backward, generic pooled forward
+    (2, 2, 4, 30, 7, True),
+    (2, 12, 6, 1, 1024, False),       # dim-4 style plane (vn1 / vn2): one row of 1024 positions
+])
+def test_per_channel_vn_layer_vector_and_scalar_forms_against_the_fp64_oracle(B, Cin, Cout, N, k, pool):
+    """VNLinearLeakyReLU with one direction per feature channel (vn_layers.py:48-77, 112-132; mean_pool :152-153) on shapes
+    that take the four-positions-per-thread kernels (vn_apply_fwd_vec / vn_bwd_apply_vec, plain and two-input-channel forms)
+    and on shapes that must fall back to the scalar ones: output, input gradient and every parameter gradient against the
+    oracle's op sequence evaluated in fp64 (train mode)."""
+    from hpcs_amd.nn.dgcnn.utils.vn_layers import VNLinearLeakyReLU
+    dev = "cuda"
+    x = det_normalish((B, Cin, 3, N, k), 900 + Cin + N)
+    m = VNLinearLeakyReLU(Cin, Cout, dim=5)
+    sd = m.state_dict()
+    m.load_state_dict(det_params({k_: tuple(v.shape) for k_, v in sd.items()}, 901))
+    m = m.to(dev).train()
+    P = {"c." + k_: v.detach().cpu().double().requires_grad_(v.dtype.is_floating_point and "running" not in k_)
+         for k_, v in m.state_dict().items()}
+    xg = x.to(dev).requires_grad_(True)
+    y = m(xg, pool_k=k) if pool else m(xg)
+    xr = x.double().requires_grad_(True)
+    yr = OE.vn_linear_leaky_relu(xr, P, "c", True)
+    if pool:
+        yr = yr.mean(dim=-1)
+    assert tuple(y.shape) == tuple(yr.shape)
+    w = det_normalish(tuple(yr.shape), 902)
+    (y * w.to(dev)).sum().backward()
+    (yr * w.double()).sum().backward()
+    assert relerr(y.detach().cpu().double(), yr.detach()) < 2e-6
+    assert relerr(xg.grad.cpu().double(), xr.grad) < 3e-5
+    for n_, p_ in m.named_parameters():
+        assert relerr(p_.grad.cpu().double(), P["c." + n_].grad) < 8e-5, n_
