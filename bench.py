@@ -546,6 +546,11 @@ def main():
                         "launches": len(big), "avg_launch_us": round(1e6 * gm_time / len(big), 2),
                         "share_of_step": round(gm_time / (step_s * EXTRA_STEPS), 4),
                         "rank_by_time": rank_gemm,
+                        "note": "`peak` prices the matrix pipe at 2.4 GHz; on random operands the chip holds 1.5-1.95 GHz under "
+                                "dense bf16 MFMA load (MI355X_MICROARCH.md 'DVFS give-back': its best plain bf16 GEMMs reach "
+                                "1250-1480 TFLOP/s = 208-247 in these units), and the average is over all 14 launches of a step "
+                                "including the launch-sized head layers; the four VN-sized launches run at 159-175 "
+                                "(profiles/r04_gemm_x3_bench_with_dma_variant.txt)",
                         "measured": EXTRA_NOTE}
         else:
             gemm_obj = {"kernel": "gemm_tn_kernel<128,128,16,2,2> (hpcs_gemm_tn, M > 64: VN dense layers + heads, forward and "
