@@ -102,7 +102,8 @@ __device__ __forceinline__ void vn_bn_bwd_point(const VnPoint& s, const float (&
     else gn += rs * gxh;
     const float pn = s.n - VN_EPS;
     const float sc = vn_div(s.nb, s.n);
-    const float dirw = pn > 0.f ? vn_div(gn, pn) : 0.f;
+    // pn is the only divisor without an epsilon: below the range where v_rcp_f32 stays finite the IEEE sequence takes over
+    const float dirw = pn >= 1e-30f ? vn_div(gn, pn) : (pn > 0.f ? gn / pn : 0.f);
 #pragma unroll
     for (int a = 0; a < 3; ++a) gp[a] = gq[a] * sc + dirw * s.p[a];
 }
