@@ -99,7 +99,6 @@ __device__ __forceinline__ void x3_tn_tile(__amdgpu_buffer_rsrc_t rsA, unsigned 
             rb[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsB, voB, k * ldb * 4, 0));
         }
     };
-    auto zero_tail = [&](int) {};
     auto lwrite = [&](const u32x4 (&pa)[3], const u32x4 (&pb)[3]) {
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
@@ -110,7 +109,6 @@ __device__ __forceinline__ void x3_tn_tile(__amdgpu_buffer_rsrc_t rsA, unsigned 
     const int nk = (K + X3_BK - 1) / X3_BK;
     u32x4 pa[3], pb[3];
     gload(0);
-    zero_tail(0);
     split8(ra, pa[0], pa[1], pa[2]);
     split8(rb, pb[0], pb[1], pb[2]);
     if (nk > 1) gload(X3_BK);
@@ -130,7 +128,6 @@ __device__ __forceinline__ void x3_tn_tile(__amdgpu_buffer_rsrc_t rsA, unsigned 
         const bool have1 = kt + 1 < nk;
         if (FULL) {
             X3_MMA6(acc[0][0], a[0], b[0]) X3_MMA6(acc[0][1], a[0], b[1])
-            zero_tail((kt + 1) * X3_BK);
             split8(ra, pa[0], pa[1], pa[2]);
             X3_MMA6(acc[1][0], a[1], b[0]) X3_MMA6(acc[1][1], a[1], b[1])
             split8(rb, pb[0], pb[1], pb[2]);
@@ -139,7 +136,6 @@ __device__ __forceinline__ void x3_tn_tile(__amdgpu_buffer_rsrc_t rsA, unsigned 
             if (live[0][1]) { X3_MMA6(acc[0][1], a[0], b[1]) }
             if (live[1][0]) { X3_MMA6(acc[1][0], a[1], b[0]) }
             if (live[1][1]) { X3_MMA6(acc[1][1], a[1], b[1]) }
-            zero_tail((kt + 1) * X3_BK);
             split8(ra, pa[0], pa[1], pa[2]);
             split8(rb, pb[0], pb[1], pb[2]);
         }
@@ -331,7 +327,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_big_x3_kernel(
             ld_xp = X + (ld_batch / n_inner) * sXo + (ld_batch % n_inner) * sXi;
         }
     };
-    auto zero_rows = [&]() {};
     unsigned char* wbase = x3_lds + lrow * X3_PITCH + lh * 16;
     auto lwrite = [&](const u32x4 (&pa)[3], const u32x4 (&pb)[3]) {
 #pragma unroll
@@ -354,7 +349,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_big_x3_kernel(
     u32x4 pa[3], pb[3];
     if (g < g_end) {
         gload();
-        zero_rows();
         split8(rg, pa[0], pa[1], pa[2]);
         split8(rx, pb[0], pb[1], pb[2]);
         if (g + 1 < g_end) gload();
@@ -373,8 +367,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_big_x3_kernel(
             }
         if (all_live) {
             X3_MMA6(acc[0][0], a[0], b[0]) X3_MMA6(acc[0][1], a[0], b[1])
-            zero_rows();
-            split8(rg, pa[0], pa[1], pa[2]);
+                split8(rg, pa[0], pa[1], pa[2]);
             X3_MMA6(acc[1][0], a[1], b[0]) X3_MMA6(acc[1][1], a[1], b[1])
             split8(rx, pb[0], pb[1], pb[2]);
         } else {
@@ -382,8 +375,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_big_x3_kernel(
             if (live[0][1]) { X3_MMA6(acc[0][1], a[0], b[1]) }
             if (live[1][0]) { X3_MMA6(acc[1][0], a[1], b[0]) }
             if (live[1][1]) { X3_MMA6(acc[1][1], a[1], b[1]) }
-            zero_rows();
-            split8(rg, pa[0], pa[1], pa[2]);
+                split8(rg, pa[0], pa[1], pa[2]);
             split8(rx, pb[0], pb[1], pb[2]);
         }
         if (g + 2 < g_end) gload();
