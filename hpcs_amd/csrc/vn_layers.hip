@@ -571,7 +571,7 @@ __global__ void vn_bwd_reduce_kernel(PdRef pd, const float* __restrict__ gout,
             pd_load3(pd, b, c, l, s.p);
             if (flags & HPCS_VN_LRELU) pd_load3(pd, b, cd, l, s.d);
             else s.d[0] = s.d[1] = s.d[2] = 0.f;
-            vn_forward_point(s, mu, rs, ga, be, flags);
+            vn_forward_point<true>(s, mu, rs, ga, be, flags);
             float g[3], gq[3], gd[3];
             load_gout(gout, b, Cout, c, L, l, pool_k, g);
             vn_lrelu_bwd_point(s, g, slope, flags, gq, gd);
@@ -653,7 +653,7 @@ __global__ __launch_bounds__(TPB) void vn_bwd_reduce_vec_kernel(const float* __r
                     sp.d[a] = act ? dv[a][q] : 0.f;
                     g[a] = gv[a][q];
                 }
-                vn_forward_point(sp, mu, rs, ga, be, flags);
+                vn_forward_point<true>(sp, mu, rs, ga, be, flags);
                 vn_lrelu_bwd_point(sp, g, slope, flags, gq, gd);
                 const float gnb = vn_div(gq[0] * sp.p[0] + gq[1] * sp.p[1] + gq[2] * sp.p[2], sp.n);
                 s1 += gnb;
@@ -779,7 +779,7 @@ __global__ __launch_bounds__(TPB) void vn_bwd_reduce_k2all_kernel(const float* _
                 sp.d[a] = __fmaf_rn(wd1, e1v[a][q], __fmul_rn(wd0, e0v[a][q]));
                 g[a] = gv[a][q];
             }
-            vn_forward_point(sp, mu, rs, ga, be, flags);
+            vn_forward_point<true>(sp, mu, rs, ga, be, flags);
             vn_lrelu_bwd_point(sp, g, slope, flags, gq, gd);
             const float gnb = vn_div(gq[0] * sp.p[0] + gq[1] * sp.p[1] + gq[2] * sp.p[2], sp.n);
             s1 += gnb;
@@ -839,7 +839,7 @@ __global__ void vn_bwd_apply_kernel(PdRef pd, const float* __restrict__ gout,
             s.d[0] = s.d[1] = s.d[2] = 0.f;
         }
         const float mu = bn ? mean[c] : 0.f, rs = bn ? rstd[c] : 1.f, ga = bn ? gamma[c] : 1.f, be = bn ? beta[c] : 0.f;
-        vn_forward_point(s, mu, rs, ga, be, flags);
+        vn_forward_point<true>(s, mu, rs, ga, be, flags);
         float g[3], gq[3], gd[3];
         load_gout(gout, b, Cout, c, L, l, pool_k, g);
         vn_lrelu_bwd_point(s, g, slope, flags, gq, gd);
@@ -945,7 +945,7 @@ __global__ __launch_bounds__(TPB) void vn_bwd_apply_vec_kernel(
             s.d[a] = act ? dv[a][q] : 0.f;
             g[a] = gv[a][q];
         }
-        vn_forward_point(s, mu, rs, ga, be, flags);
+        vn_forward_point<true>(s, mu, rs, ga, be, flags);
         vn_lrelu_bwd_point(s, g, slope, flags, gq, gd);
         vn_bn_bwd_point(s, gq, bn, training != 0, m1, m2, ga, rs, gp);
 #pragma unroll
@@ -1031,7 +1031,7 @@ __global__ __launch_bounds__(TPB) void vn_bwd_apply_shared_vec_kernel(
             float g[3], gq[3], gd[3], gp[3];
 #pragma unroll
             for (int a = 0; a < 3; ++a) { sp.p[a] = pv[a][q]; sp.d[a] = dsh[a][q]; g[a] = gv[a][q]; }
-            vn_forward_point(sp, mu, rs, ga, be, flags);
+            vn_forward_point<true>(sp, mu, rs, ga, be, flags);
             vn_lrelu_bwd_point(sp, g, slope, flags, gq, gd);
             vn_bn_bwd_point(sp, gq, bn, training != 0, m1, m2, ga, rs, gp);
 #pragma unroll
