@@ -30,6 +30,7 @@ struct HpcsTuning {
     int sampled_seg;       // HPCS_SAMPLED_SEG    triplets per 8-lane group (0 = chosen per launch)
     int sampled_lds_kb;    // HPCS_SAMPLED_LDS_KB LDS budget of its positive table (156)
     int edge_bwd_atomic;   // HPCS_EDGE_BWD_ATOMIC graph-layer gradient reduction by atomics instead of the transposed graph (0)
+    int x3_nt_lds_kb;      // HPCS_X3_NT_LDS_KB    LDS request of the bf16x3 weight-gradient kernel in KB (56: two workgroups per CU; 36 = its stage = three)
 };
 extern "C" const HpcsTuning* hpcs_tuning_table(void);
 static inline const HpcsTuning& hpcs_tuning() { return *hpcs_tuning_table(); }

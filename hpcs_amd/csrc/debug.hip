@@ -129,6 +129,7 @@ static HpcsTuning read_tuning() {
     t.sampled_seg = env_int("HPCS_SAMPLED_SEG", 0);
     t.sampled_lds_kb = env_int("HPCS_SAMPLED_LDS_KB", 156);
     t.edge_bwd_atomic = getenv("HPCS_EDGE_BWD_ATOMIC") != nullptr;
+    t.x3_nt_lds_kb = env_int("HPCS_X3_NT_LDS_KB", 56);
     return t;
 }
 static HpcsTuning& tuning_storage() {
@@ -146,7 +147,7 @@ extern "C" int hpcs_debug_set_tuning(const char* name, int value) {
         {"HPCS_NT_WG_TARGET", &t.nt_wg_target}, {"HPCS_NT_BIG_MIN", &t.nt_big_min}, {"HPCS_NT_BIG_WG", &t.nt_big_wg},
         {"HPCS_GEMM_VECSTORE", &t.gemm_vecstore}, {"HPCS_GEMM_TN_GUARDED", &t.gemm_tn_guarded}, {"HPCS_GEMM_X3", &t.gemm_x3}, {"HPCS_KNN_KERNEL", &t.knn_kernel},
         {"HPCS_SAMPLED_V", &t.sampled_v}, {"HPCS_SAMPLED_SEG", &t.sampled_seg}, {"HPCS_SAMPLED_LDS_KB", &t.sampled_lds_kb},
-        {"HPCS_EDGE_BWD_ATOMIC", &t.edge_bwd_atomic}};
+        {"HPCS_EDGE_BWD_ATOMIC", &t.edge_bwd_atomic}, {"HPCS_X3_NT_LDS_KB", &t.x3_nt_lds_kb}};
     for (auto& e : tab)
         if (strcmp(e.n, name) == 0) { *e.p = value; return HPCS_OK; }
     return HPCS_ERR_SHAPE;

@@ -403,15 +403,21 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_big_x3_kernel(
 int hpcs_x3_nt_big_launch(const float* G, int ldg, int64_t sGo, int64_t sGi, const float* X, int ldx, int64_t sXo, int64_t sXi, int M,
                           int Kx, int Nc, int n_inner, int n_batch, int nsplit, float* part, int tilesM, int tilesK, int vecG, int vecX,
                           long blocks, hipStream_t st) {
+    // The stage is 36 KB = three workgroups per CU = 456 of a SIMD's 512 VGPRs: beside them a streaming kernel of the main
+    // stream (this kernel runs on the side stream under the VN backward's element-wise passes) finds room for ONE wave per
+    // SIMD.  Requesting 56 KB holds the residency at two workgroups per CU: the kernel alone is slower, the step 0.07-0.08 ms
+    // faster in three alternating runs (8.25 -> 8.17 ms; 90 KB = one per CU: the same).  HPCS_X3_NT_LDS_KB=36 restores three.
+    const int want_kb = hpcs_tuning().x3_nt_lds_kb;
+    const int lds = want_kb * 1024 > X3_STAGE ? (want_kb > 156 ? 156 * 1024 : want_kb * 1024) : X3_STAGE;
     static const bool attr_ok =
-        hipFuncSetAttribute((const void*)gemm_nt_big_x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_STAGE) == hipSuccess &&
-        hipFuncSetAttribute((const void*)gemm_nt_big_x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_STAGE) == hipSuccess;
+        hipFuncSetAttribute((const void*)gemm_nt_big_x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) == hipSuccess &&
+        hipFuncSetAttribute((const void*)gemm_nt_big_x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) == hipSuccess;
     if (!attr_ok) return HPCS_ERR_UNSUPPORTED;
     if (vecG && vecX && Nc % X3_BK == 0)
-        hipLaunchKernelGGL(gemm_nt_big_x3_kernel<true>, dim3((unsigned)blocks), dim3(256), X3_STAGE, st, G, ldg, sGo, sGi, X, ldx, sXo, sXi,
+        hipLaunchKernelGGL(gemm_nt_big_x3_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, st, G, ldg, sGo, sGi, X, ldx, sXo, sXi,
                            M, Kx, Nc, n_inner, n_batch, nsplit, part, tilesM, tilesK, vecG, vecX);
     else
-        hipLaunchKernelGGL(gemm_nt_big_x3_kernel<false>, dim3((unsigned)blocks), dim3(256), X3_STAGE, st, G, ldg, sGo, sGi, X, ldx, sXo, sXi,
+        hipLaunchKernelGGL(gemm_nt_big_x3_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, st, G, ldg, sGo, sGi, X, ldx, sXo, sXi,
                            M, Kx, Nc, n_inner, n_batch, nsplit, part, tilesM, tilesK, vecG, vecX);
     return HPCS_OK;
 }
