@@ -611,35 +611,36 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(
     // with a one-step register prefetch: the global loads of step i+1 are in flight while step i is multiplied.
     const int64_t units = (int64_t)n_batch * units_per_batch;
     float4 rg[G_LD], rx[X_LD];
-    auto gload = [&](int64_t u, int c0) {
-        const int batch = (int)(u / units_per_batch);
-        const int c_begin = (int)(u % units_per_batch) * chunk;
-        const int c_end = min(Nc, c_begin + chunk);
+    // iterator over (unit, c0): the unit's operand bases and column range are found (a 64-bit division) when the unit is
+    // opened, not in every step
+    const float* Gp_u = G;
+    const float* Xp_u = X;
+    int c0 = 0, c_end_u = 0;
+    auto open_unit = [&](int64_t uu) {
+        const int batch = (int)(uu / units_per_batch);
+        c0 = (int)(uu % units_per_batch) * chunk;
+        c_end_u = min(Nc, c0 + chunk);
         const int bo = batch / n_inner, bi = batch % n_inner;
-        const float* Gp = G + bo * sGo + bi * sGi;
-        const float* Xp = X + bo * sXo + bi * sXi;
+        Gp_u = G + bo * sGo + bi * sGi;
+        Xp_u = X + bo * sXo + bi * sXi;
+    };
+    auto gload = [&]() {
 #pragma unroll
         for (int i = 0; i < G_LD; ++i) {
             const int f = tid + i * NT, row = f / (BKC / 4), c4 = (f % (BKC / 4)) * 4;
-            rg[i] = ld4_guard(Gp + (int64_t)(m0 + row) * ldg, c0 + c4, c_end, m0 + row < M, vecG);
+            rg[i] = ld4_guard(Gp_u + (int64_t)(m0 + row) * ldg, c0 + c4, c_end_u, m0 + row < M, vecG);
         }
 #pragma unroll
         for (int i = 0; i < X_LD; ++i) {
             const int f = tid + i * NT, row = f / (BKC / 4), c4 = (f % (BKC / 4)) * 4;
-            rx[i] = ld4_guard(Xp + (int64_t)(x0 + row) * ldx, c0 + c4, c_end, x0 + row < Kx, vecX);
+            rx[i] = ld4_guard(Xp_u + (int64_t)(x0 + row) * ldx, c0 + c4, c_end_u, x0 + row < Kx, vecX);
         }
     };
-    // iterator over (unit, c0)
     int64_t u = split;
-    int c0 = 0, c_end_u = 0;
-    auto unit_bounds = [&](int64_t uu, int& cb, int& ce) {
-        cb = (int)(uu % units_per_batch) * chunk;
-        ce = min(Nc, cb + chunk);
-    };
     bool have = u < units;
     if (have) {
-        unit_bounds(u, c0, c_end_u);
-        gload(u, c0);
+        open_unit(u);
+        gload();
     }
     while (have) {
         __syncthreads();
@@ -661,9 +662,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(
         if (c0 >= c_end_u) {
             u += nsplit;
             have = u < units;
-            if (have) unit_bounds(u, c0, c_end_u);
+            if (have) open_unit(u);
         }
-        if (have) gload(u, c0);
+        if (have) gload();
         if (!V4) {
 #pragma unroll
             for (int kk = 0; kk < BKC / 2; ++kk) {
@@ -760,31 +761,33 @@ __global__ __launch_bounds__(256) void gemm_nt_edge_kernel(
 
     const int64_t units = (int64_t)n_batch * units_per_batch;
     float4 rg[2], rx[2];
-    auto gload = [&](int64_t u, int c0) {
-        const int batch = (int)(u / units_per_batch);
-        const int c_begin = (int)(u % units_per_batch) * chunk;
-        const int c_end = min(Nc, c_begin + chunk);
+    // the unit's operand bases and column range change once per unit (~chunk / 32 steps): the 64-bit division that finds them is
+    // not in the per-step path (it cost ~200 scalar instructions per 32-column step)
+    const float* Gp_u = G;
+    const float* Xp_u = X;
+    int c0 = 0, c_end_u = 0;
+    auto open_unit = [&](int64_t uu) {
+        const int batch = (int)(uu / units_per_batch);
+        c0 = (int)(uu % units_per_batch) * chunk;
+        c_end_u = min(Nc, c0 + chunk);
         const int bo = batch / n_inner, bi = batch % n_inner;
-        const float* Gp = G + bo * sGo + bi * sGi;
-        const float* Xp = X + bo * sXo + bi * sXi;
+        Gp_u = G + bo * sGo + bi * sGi;
+        Xp_u = X + bo * sXo + bi * sXi;
+    };
+    auto gload = [&]() {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int f = tid + i * NT, row = f / (BKC / 4), c4 = (f % (BKC / 4)) * 4;
             const bool in = f < NLD;
-            rg[i] = ld4_guard(Gp + (int64_t)row * ldg, c0 + c4, c_end, in && row < M, vecG);
-            rx[i] = ld4_guard(Xp + (int64_t)row * ldx, c0 + c4, c_end, in && row < Kx, vecX);
+            rg[i] = ld4_guard(Gp_u + (int64_t)row * ldg, c0 + c4, c_end_u, in && row < M, vecG);
+            rx[i] = ld4_guard(Xp_u + (int64_t)row * ldx, c0 + c4, c_end_u, in && row < Kx, vecX);
         }
     };
     int64_t u = split;
-    int c0 = 0, c_end_u = 0;
-    auto unit_bounds = [&](int64_t uu, int& cb, int& ce) {
-        cb = (int)(uu % units_per_batch) * chunk;
-        ce = min(Nc, cb + chunk);
-    };
     bool have = u < units;
     if (have) {
-        unit_bounds(u, c0, c_end_u);
-        gload(u, c0);
+        open_unit(u);
+        gload();
     }
     while (have) {
         __syncthreads();
@@ -801,9 +804,9 @@ __global__ __launch_bounds__(256) void gemm_nt_edge_kernel(
         if (c0 >= c_end_u) {
             u += nsplit;
             have = u < units;
-            if (have) unit_bounds(u, c0, c_end_u);
+            if (have) open_unit(u);
         }
-        if (have) gload(u, c0);
+        if (have) gload();
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int col = 4 * (2 * w + q) + lq;            // this lane's column of the k4-step
