@@ -629,7 +629,7 @@ __global__ __launch_bounds__(TPB) void vn_bwd_reduce_vec_kernel(const float* __r
             if (pool_k > 0) {
                 const int64_t Np = L / pool_k;
                 const float kf = (float)pool_k;
-                const float* gp = gout + (((int64_t)b * Cout + c) * 3) * Np + l / pool_k;
+                const float* gp = gout + (((int64_t)b * Cout + c) * 3) * Np + (int)((unsigned)l / (unsigned)pool_k);   // l < L < 2^31 (host)
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
                     const float g = gp[a * Np] / kf;
@@ -2284,7 +2284,8 @@ static int vn_bwd_reduce_impl(PdRef pd, const float* gout, const float* mean, co
     if (!zeroed)
         if (const int zr = hpcs_zero_async(st, red, sizeof(double) * 2 * Cout)) return zr;
     if (B == 0) return HPCS_OK;
-    const bool vec = pd.idx == nullptr && pd.L % 4 == 0 && (((uintptr_t)pd.base & 15u) == 0) && B <= 65535 && Cout <= 65535 &&
+    const bool vec = pd.idx == nullptr && pd.L % 4 == 0 && pd.L < ((int64_t)1 << 31) && (((uintptr_t)pd.base & 15u) == 0) && B <= 65535 &&
+                     Cout <= 65535 &&
                      (pool_k > 0 ? pool_k % 4 == 0 : (((uintptr_t)gout & 15u) == 0));
     if (vec && pd.w2 == nullptr)
         hipLaunchKernelGGL(vn_bwd_reduce_vec_kernel<false>, dim3(hpcs_cdiv(pd.L, TPB * 4 * VEC_ITEMS), Cout, B), dim3(TPB), 0, st,
