@@ -79,7 +79,8 @@ def init_distributed(backend=None):
             backend = os.environ.get("HPCS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
             # "nccl" is RCCL on ROCm; HPCS_DIST_BACKEND=gloo rehearses the multi-rank path on one GPU
         if backend == "nccl":
-            torch.cuda.set_device(local)
+            # (HPCS_SINGLE_DEVICE_REHEARSAL: every rank on cuda:0 -- RCCL itself decides whether it accepts that)
+            torch.cuda.set_device(0 if os.environ.get("HPCS_SINGLE_DEVICE_REHEARSAL") else local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
 
