@@ -73,7 +73,9 @@ int hpcs_gemm_tn(const float* At, int lda, const float* Bm, int ldb, int64_t str
 /* hpcs_gemm_tn_x3: the same product with the same arguments, evaluated on the BF16 matrix cores at fp32 accuracy: every
  * fp32 operand splits exactly into three bf16 pieces and six piece products (exact in fp32, accumulated in fp32 by the MFMA)
  * carry the product to 2^-23 |a||b| (csrc/gemm_x3.hip).  Not bit-identical to the fma chain of hpcs_gemm_tn -- as close to
- * the exact product (tests).  Used for the large dense layers (M > 64); kNN and the EdgeConv mixes keep the fma chain. */
+ * the exact product (tests).  Used for the large dense layers (M > 64); kNN and the EdgeConv mixes keep the fma chain.
+ * Its loads address one operand matrix with 32-bit byte offsets: HPCS_ERR_UNSUPPORTED when (K + 16) * lda * 4 or
+ * (K + 16) * ldb * 4 reaches 2^31 (hpcs_gemm_tn routes such shapes to the fma chain itself). */
 int hpcs_gemm_tn_x3(const float* At, int lda, const float* Bm, int ldb, int64_t strideB_o, int64_t strideB_i,
                     float* C, int ldc, int64_t strideC_o, int64_t strideC_i, int M, int Nc, int K, int n_outer,
                     int n_inner, const float* rowbias, int accumulate, hpcs_stream_t stream);
