@@ -228,8 +228,9 @@ class HypHCStep(torch.nn.Module):
                                                               (ctx.drop_seeds[1], ctx.seed_dev["drop2"])))
         else:
             x_euclidean = self.nn_feat(x, decode)
+        x_euclidean = x_euclidean.contiguous()      # ONE copy of the transposed head output: the embedder and the loss both want rows
         x_poincare = self.nn_emb(x_euclidean) if self.nn_emb is not None else x_euclidean
-        xe = x_euclidean.contiguous().view(-1, x_euclidean.shape[-1])
+        xe = x_euclidean.view(-1, x_euclidean.shape[-1])
         xp = x_poincare.contiguous().view(-1, x_poincare.shape[-1])
         y = targets.reshape(-1).long()
         if ctx is not None and plan is None:
